@@ -1,0 +1,514 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.  Not part of the product.
+
+CPU restatement (numpy/scipy) of the one hot path of annappo/GPS-SDR-Receiver
+that this repository accelerates: cold acquisition (``gpsrecv.sweepAllSats``)
+and per-channel tracking (``gpslib.SatStream.process``).  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module, and only as the checker / the timed CPU baseline.  The product
+path (``gps-sdr-receiver_amd/``) never imports it and has no CPU fallback.
+
+Parity status: PINNED.  ``oracle/make_golden.py`` imports the real reference
+from /root/reference (possible in the build container only) and freezes its
+outputs on seeded synthetic IQ under ``tests/golden/``; ``tests/test_oracle.py``
+checks every function below against those fixtures (bit-for-bit where the
+expression is the same numpy expression, to 1e-12 otherwise).  The reference
+holds no tests or golden vectors of its own.
+
+All file:line citations are into /root/reference/src/.  The dtype chain is kept
+on purpose: complex64 samples, float32 phase argument, complex64 carrier wipe
+and forward FFT, complex128 replica spectrum / inverse FFT, float64
+correlation statistics.  Scalars follow numpy >= 2 promotion
+(NEP 50), the numpy of this image.
+"""
+from dataclasses import dataclass
+
+import numpy as np
+from scipy.fft import fft, ifft
+
+F32 = np.float32
+C64 = np.complex64
+
+
+# --------------------------------------------------------------------------
+# configuration (gpsglob.py:35-131) as a plain object instead of module globals
+# --------------------------------------------------------------------------
+@dataclass
+class Params:
+    code_samples: int = 2048        # gpsglob.py:119
+    n_cyc: int = 32                 # gpsglob.py:122
+    corr_avg: int = 8               # gpsglob.py:63
+    corr_min: float = 8             # gpsglob.py:65
+    sweep_corr_avg: int = 4         # gpsglob.py:67
+    min_freq: float = -5000.0       # gpsglob.py:72
+    max_freq: float = +5000.0       # gpsglob.py:73
+    step_freq: float = 200          # gpsglob.py:74
+    it_sweep: int = 40              # gpsglob.py:41
+    it_sweep_all: int = 10          # gpsglob.py:42
+    max_sat: int = 11               # gpsglob.py:38
+
+    @property
+    def sample_rate(self):          # gpsglob.py:121
+        return 1000 * self.code_samples
+
+    @property
+    def ngps(self):                 # gpsglob.py:125
+        return self.n_cyc * self.code_samples
+
+
+def sec_time(p):
+    """t[k] = (k+1)/fs as float32 (gpsrecv.py:32-33, gpslib.py:1053-1054)."""
+    n = p.ngps
+    return np.linspace(1, n, n, endpoint=True, dtype=F32) / p.sample_rate
+
+
+# --------------------------------------------------------------------------
+# C/A chips and the interpolated replica (cacodes.py:5-80, gpslib.py:62-87)
+# --------------------------------------------------------------------------
+_G2_SEL = [(2, 6), (3, 7), (4, 8), (5, 9), (1, 9), (2, 10), (1, 8), (2, 9),
+           (3, 10), (2, 3), (3, 4), (5, 6), (6, 7), (7, 8), (8, 9), (9, 10),
+           (1, 4), (2, 5), (3, 6), (4, 7), (5, 8), (6, 9), (1, 3), (4, 6),
+           (5, 7), (6, 8), (7, 9), (8, 10), (1, 6), (2, 7), (3, 8), (4, 9),
+           (5, 10), (4, 10), (1, 7), (2, 8), (4, 10)]
+
+
+def chips(prn):
+    """+-1 chips; integer-register form of the IS-GPS-200 generators.  The
+    reference stores the same sequences as literals (cacodes.py:5-80)."""
+    a, b = _G2_SEL[prn - 1]
+    r1 = r2 = 0x3FF                       # bit s-1 holds stage s
+    seq = np.empty(1023, dtype=np.int8)
+    for n in range(1023):
+        o = ((r1 >> 9) ^ (r2 >> (a - 1)) ^ (r2 >> (b - 1))) & 1
+        seq[n] = 2 * o - 1
+        f1 = ((r1 >> 2) ^ (r1 >> 9)) & 1
+        f2 = ((r2 >> 1) ^ (r2 >> 2) ^ (r2 >> 5) ^ (r2 >> 7) ^ (r2 >> 8)
+              ^ (r2 >> 9)) & 1
+        r1 = ((r1 << 1) | f1) & 0x3FF
+        r2 = ((r2 << 1) | f2) & 0x3FF
+    return seq
+
+
+def gps_cacode(prn, code_samples=2048):
+    """GPSCacode (gpslib.py:73-77) on doubledCacode (gpslib.py:62-69)."""
+    y = np.repeat(chips(prn), 2).astype(F32)
+    x = np.arange(y.size, dtype=F32)
+    xp = np.linspace(x[0], x[-1], code_samples, endpoint=True, dtype=F32)
+    return np.interp(xp, x, y)
+
+
+def gps_cacode_rep(prn, copies, delay, code_samples=2048):
+    """GPSCacodeRep (gpslib.py:81-87)."""
+    return np.roll(np.tile(gps_cacode(prn, code_samples), copies), delay)
+
+
+def fft_cacode(prn, code_samples=2048):
+    """gpsrecv.py:574-577, gpslib.py:1065."""
+    return fft(gps_cacode(prn, code_samples))
+
+
+# --------------------------------------------------------------------------
+# acquisition (gpsrecv.py:217-274)
+# --------------------------------------------------------------------------
+def demod_doppler(data, freq, phase, n, t):
+    """Carrier wipe-off over the first n samples (gpsrecv.py:232-235, identical
+    in gpslib.py:1343-1346).  Returns (wiped complex64[n], new phase)."""
+    factor = np.exp(-1j * (phase + 2 * np.pi * freq * t[:n]))
+    phase = phase + 2 * np.pi * freq * t[n - 1]
+    return factor * data[:n], np.remainder(phase, 2 * np.pi)
+
+
+def peak_stats(corr):
+    """mean, population std, first-index argmax (gpsrecv.py:218-223)."""
+    mx = int(np.argmax(corr))
+    return mx, corr[mx], np.mean(corr), np.std(corr)
+
+
+def find_code_phase(corr, corr_min):
+    """gpsrecv.py:217-227 -> (delay or -1, normMaxCorr)."""
+    mx, peak, mean, std = peak_stats(corr)
+    norm = (peak - mean) / std
+    return (mx if norm > corr_min else -1), norm
+
+
+def folded_spectrum(wiped, first, count, cs):
+    """Mean of `count` consecutive code-period FFTs starting at period `first`
+    (gpsrecv.py:250-254, gpslib.py:1316-1323)."""
+    acc = 0
+    for i in range(first, first + count):
+        acc = acc + fft(wiped[i * cs:(i + 1) * cs])
+    return acc / count
+
+
+def circ_corr(spec, replica_spec):
+    """|ifft(X * conj(R))| (gpsrecv.py:258, gpslib.py:1324-1325)."""
+    return np.abs(ifft(spec * np.conjugate(replica_spec)))
+
+
+def acq_table(data, freqs, prns, n_avg, p, t=None, spectra=None):
+    """Every (Doppler bin, SV) cell of the search surface, without the
+    first-hit bookkeeping: the array expressions of gpsrecv.py:249-259 for an
+    arbitrary frequency list.  Returns dict of arrays [nbins, nsv]:
+    argmax (int32), peak, mean, std (float64)."""
+    cs = p.code_samples
+    t = sec_time(p) if t is None else t
+    if spectra is None:
+        spectra = {s: fft_cacode(s, cs) for s in prns}
+    nb, ns = len(freqs), len(prns)
+    out = dict(argmax=np.zeros((nb, ns), np.int32), peak=np.zeros((nb, ns)),
+               mean=np.zeros((nb, ns)), std=np.zeros((nb, ns)))
+    for b, f in enumerate(freqs):
+        wiped, _ = demod_doppler(data, f, 0, n_avg * cs, t)
+        spec = folded_spectrum(wiped, 0, n_avg, cs)
+        for j, s in enumerate(prns):
+            mx, peak, mean, std = peak_stats(circ_corr(spec, spectra[s]))
+            out['argmax'][b, j] = mx
+            out['peak'][b, j] = peak
+            out['mean'][b, j] = mean
+            out['std'][b, j] = std
+    return out
+
+
+def sweep_all_sats(data, freq, sat_lst, sat_found, it_sweep, p, spectra, t):
+    """sweepAllSats (gpsrecv.py:241-274): up to it_sweep bins per call, first
+    bin over threshold claims the SV (first-hit), lists mutated in place."""
+    ready = False
+    avg = min(p.sweep_corr_avg, p.n_cyc)
+    cs = p.code_samples
+    it = 0
+    while freq < p.max_freq and it < it_sweep:
+        wiped, _ = demod_doppler(data, freq, 0, avg * cs, t)
+        spec = folded_spectrum(wiped, 0, avg, cs)
+        hit = []
+        for s in sat_lst:
+            delay, norm = find_code_phase(circ_corr(spec, spectra[s]),
+                                          p.corr_min)
+            if delay > -1:
+                sat_found.append((norm, s, freq, delay))
+                hit.append(s)
+        for s in hit:
+            sat_lst.remove(s)
+        freq += p.step_freq
+        if freq >= p.max_freq:
+            ready = True
+            freq -= p.max_freq - p.min_freq
+        it += 1
+    return ready, freq, sorted(sat_found, reverse=True)
+
+
+def get_new_sats(act, found, cpq, max_sat):
+    """getNewSats (gpsrecv.py:423-440)."""
+    good = {s for s, (q, l) in cpq.items() if q > 0 or l > 0}
+    rest = [e for e in found if e[1] not in good]
+    want = good | {e[1] for e in rest[:max_sat - len(good)]}
+    common = act & want
+    return act - common, want - common
+
+
+# --------------------------------------------------------------------------
+# tracking (gpslib.py:1044-1446, signal part)
+# --------------------------------------------------------------------------
+def fit_code_phase(corr, mx):
+    """fitCodePhase (gpslib.py:1268-1290): mean of a triangle and a parabola
+    fit through the peak and its circular neighbours."""
+    n = len(corr)
+    lo = corr[mx - 1 if mx > 0 else n - 1]
+    hi = corr[mx + 1 if mx < n - 1 else 0]
+    pk = corr[mx]
+    tri = 0.5 * (hi - lo) / (pk - (hi if lo > hi else lo))
+    par = 0.5 * (hi - lo) / (2 * pk - hi - lo)
+    return mx + 0.5 * (tri + par)
+
+
+class SatStream:
+    """Numeric and control restatement of gpslib.SatStream (gpslib.py:1044-1446)
+    including the edge list and its slicing into 20-ms bits; subframe
+    extraction (evalGpsBits/Subframe) is host logic of the 'next' scope."""
+    DF_GAIN1 = 10                        # gpslib.py:1046
+    DF_GAIN2 = 1                         # gpslib.py:1047
+    MIN_CORR_Q = -0.9                    # gpslib.py:1048
+
+    def __init__(self, sat_no, freq, p=None, delay=0):
+        p = Params() if p is None else p
+        self.p = p
+        self.sat_no = sat_no
+        self.t = sec_time(p)
+        self.edges = [0]
+        self.gpsbits = np.array([], dtype=np.int8)
+        self.gpsbits_st = np.array([], dtype=np.int64)
+        self.phase_locked = False
+        self.phase = 0.0
+        self.freq = freq
+        self.prev_samples = []
+        self.ms_time = 0
+        self.smp_time = 0
+        self.spectrum = fft_cacode(sat_no, p.code_samples)
+        self.delay = delay
+        self.no_sec = 1024 // p.n_cyc
+        self.corr_avg = min(p.corr_avg, p.n_cyc)
+        self.code_rep = gps_cacode_rep(sat_no, p.n_cyc, 0, p.code_samples)
+        self.std_dev = 0.005
+        self.amplitude = 0.0
+        self.max_corr = 0.0
+        self.sweep = False
+        self.prev_stream_no = 0
+        self.prev_signal = 0
+        self.df = [0]
+        self.corr_q = 0
+        self.corr_l = 0
+        self.corrlst_no = 60 * self.no_sec
+        self.corrlst = [0]
+        self.rep_sweep = False
+        self.last = {}                   # per-block intermediates for tests
+
+    # -- state resets (gpslib.py:1095-1120)
+    def erase_prev_data(self):
+        self.edges = [0]
+        self.gpsbits = np.array([], dtype=np.int8)
+        self.gpsbits_st = np.array([], dtype=np.int64)
+        self.prev_samples = []
+
+    def set_phase_unlocked(self):
+        self.phase_locked = False
+        self.corrlst = [0]
+        self.ms_time = 0
+        self.phase = 0.0
+        self.erase_prev_data()
+
+    def init_sweep(self):
+        self.set_phase_unlocked()
+        self.freq_save = self.freq
+        self.df_save = self.df.copy()
+        self.freq = self.p.min_freq
+        self.df = [0]
+        self.sweep = True
+
+    def restore_freq(self):
+        self.freq = self.freq_save
+        self.df = self.df_save.copy()
+
+    def report_values(self, frames):     # gpslib.py:1124-1131
+        for d in frames:
+            d['SAT'] = self.sat_no
+            d['AMP'] = self.amplitude
+            d['CRM'] = self.max_corr
+            d['FRQ'] = self.freq
+            d['SWP'] = self.rep_sweep
+        self.rep_sweep = False
+
+    def check_corr_quality(self):        # gpslib.py:1134-1138
+        return (len(self.corrlst) >= self.corrlst_no
+                and self.corr_q < self.MIN_CORR_Q)
+
+    # -- correlation (gpslib.py:1293-1327)
+    def find_code_phase(self, corr):
+        mx, peak, mean, std = peak_stats(corr)
+        norm = (peak - mean) / std
+        if norm > self.p.corr_min:
+            return mx, fit_code_phase(corr, mx), norm
+        return -1, -1.0, norm
+
+    def cacode_corr(self, wiped, corr_avg):
+        cs = self.p.code_samples
+        first = (len(wiped) // cs - corr_avg) // 2
+        spec = folded_spectrum(wiped, first, corr_avg, cs)
+        corr = circ_corr(spec, self.spectrum)
+        return (corr,) + self.find_code_phase(corr)
+
+    def corr_quality(self, code_phase):  # gpslib.py:1331-1339
+        self.corrlst.append(-1 if code_phase < 0 else 1)
+        if len(self.corrlst) > self.corrlst_no:
+            del self.corrlst[0]
+        return np.mean(self.corrlst), np.mean(self.corrlst[-self.no_sec:])
+
+    # -- per-channel re-acquisition (gpslib.py:1350-1380)
+    def get_corr_max(self, data, corr_avg, freq):
+        wiped, _ = demod_doppler(data, freq, 0, corr_avg * self.p.code_samples,
+                                 self.t)
+        corr, delay, co_ph, norm = self.cacode_corr(wiped, corr_avg)
+        return delay, (corr[delay] if delay > -1 else 0), co_ph, norm
+
+    def sweep_frequency(self, data, freq):
+        sweeping, j, delay, co_ph = True, 0, -1, -1
+        while delay < 0 and j < self.p.it_sweep:
+            delay, _, co_ph, norm = self.get_corr_max(
+                data, self.p.sweep_corr_avg, freq)
+            if delay < 0:
+                freq = freq + self.p.step_freq
+            j += 1
+        if delay >= 0:
+            sweeping = False
+        elif freq > self.p.max_freq:
+            freq = self.p.min_freq
+            sweeping = False
+        return sweeping, freq, norm, delay, co_ph
+
+    # -- prompt integrate-and-dump (gpslib.py:1394-1446)
+    def decode_data(self, wiped, delay):
+        p = self.p
+        cs, ngps = p.code_samples, p.ngps
+        min_edge_amp = 3 * self.std_dev
+        prev_sign = (2 * (len(self.edges) % 2) - 1) * self.edges[0]
+        y = np.roll(self.code_rep, delay) * wiped
+        nps = len(self.prev_samples)
+        if nps > 0:
+            y = np.append(self.prev_samples, y)
+        ns = ngps + nps
+        n0, n1 = 0, nps + delay
+        if n1 == 0:
+            n1 = cs
+            st = self.smp_time
+        else:
+            st = self.smp_time + delay - cs
+        dumps = []
+        while n1 <= ns:
+            m = np.mean(y[n0:n1])
+            dumps.append(m)
+            if self.phase_locked:
+                sgn = np.sign(m.real)
+                if self.edges[0] == 0:
+                    self.edges[0] = sgn
+                    prev_sign = sgn
+                elif (sgn != prev_sign and prev_sign * self.prev_signal > 0
+                      and abs(m.real - self.prev_signal) > min_edge_amp):
+                    self.edges.append((self.ms_time, st + n0))
+                    prev_sign = sgn
+                self.prev_signal = m.real
+                self.ms_time += 1
+            n0 = n1
+            n1 += cs
+        self.prev_samples = y[n0:ns]
+        return np.asarray(dumps, dtype=C64)
+
+    # -- edge list -> 20-ms bits (gpslib.py:1451-1492)
+    def logical_bits(self):
+        bits, stamps = [], []
+        sign = self.edges[0]
+        if len(self.edges) > 2:
+            t1, st1 = self.edges[1]
+            for t2, st2 in self.edges[2:]:
+                m, r = np.divmod(t2 - t1, 20)
+                if r > 17:
+                    m += 1
+                if m > 0:
+                    bits += [sign] * m
+                    stamps += [st1] + [0] * (m - 1)
+                t1, st1 = t2, st2
+                sign = -sign
+            self.edges = [sign, self.edges[-1]]
+        return (np.asarray(bits, dtype=np.int8),
+                np.asarray(stamps, dtype=np.int64))
+
+    def eval_edges(self):
+        frames = []
+        if len(self.edges) > 2:
+            bits, stamps = self.logical_bits()
+            self.gpsbits = np.append(self.gpsbits, bits)
+            self.gpsbits_st = np.append(self.gpsbits_st, stamps)
+            frames, self.gpsbits, self.gpsbits_st = self.eval_gps_bits(
+                self.gpsbits, self.gpsbits_st)
+        return frames
+
+    def eval_gps_bits(self, bits, stamps):
+        """evalGpsBits (gpslib.py:1504-1580).  Subframe extraction belongs to
+        the 'next' scope; below 300 bits the reference
+        returns its inputs untouched, which is all the fixtures exercise."""
+        if len(bits) < 300:
+            return [], bits, stamps
+        raise NotImplementedError('subframe extraction: SURVEY.md 8(f) n1')
+
+    # -- PLL (gpslib.py:1215-1262)
+    def phase_locked_loop(self, dumps):
+        max_df = 20 / self.no_sec
+        locked = self.phase_locked
+        ph = np.arctan(dumps.imag / dumps.real)
+        dp = 0
+        real = np.copy(ph)
+        for i in range(1, len(dumps)):
+            d = ph[i] - ph[i - 1]
+            if abs(d) > 2.0:
+                dp -= np.sign(d)
+            real[i] += dp * np.pi
+        offset = np.mean(real[-4:])
+        dev = np.mean(real)
+        if locked:
+            df = self.DF_GAIN2 * dev + np.mean(self.df)
+            if abs(df) > max_df:
+                df = np.sign(df) * max_df
+            if len(self.df) >= self.no_sec:
+                del self.df[0]
+            self.df.append(df)
+        else:
+            df = self.DF_GAIN1 * dev
+            self.df = [df]
+        if abs(dev) < 0.1:
+            locked = True
+        return df, offset, locked, real
+
+    def confine(self, f):                # gpslib.py:1626-1631
+        if f > self.p.max_freq:
+            return self.p.max_freq
+        if f < self.p.min_freq:
+            return self.p.min_freq
+        return f
+
+    # -- one block (gpslib.py:1141-1210)
+    def process(self, data, smp_time, sweep=False):
+        p = self.p
+        self.smp_time = smp_time
+        stream_no = smp_time // p.ngps
+        if stream_no - 1 != self.prev_stream_no:
+            self.erase_prev_data()
+        self.prev_stream_no = stream_no
+        sweep = sweep and not self.sweep
+        if sweep:
+            self.init_sweep()
+        if self.sweep:
+            self.rep_sweep = self.sweep
+            self.sweep, self.freq, self.max_corr, delay, code_phase = \
+                self.sweep_frequency(data, self.freq)
+            self.corr_q, self.corr_l = self.corr_quality(code_phase)
+            if delay >= 0:
+                self.delay = delay
+            elif not self.sweep:
+                self.restore_freq()
+            frames = []
+            if stream_no % self.no_sec == 0:
+                frames = [{}]
+                self.report_values(frames)
+            self.last = dict(mode='sweep', delay=delay, code_phase=code_phase)
+        else:
+            wiped, self.phase = demod_doppler(data, self.freq, self.phase,
+                                              p.ngps, self.t)
+            corr, delay, code_phase, norm = self.cacode_corr(wiped,
+                                                             self.corr_avg)
+            self.corr_q, self.corr_l = self.corr_quality(code_phase)
+            if delay >= 0:
+                self.delay = delay
+            dumps = self.decode_data(wiped, self.delay)
+            self.std_dev = np.std(np.abs(dumps))
+            self.amplitude = np.mean(np.abs(dumps)) / self.std_dev
+            self.max_corr = norm
+            frames = []
+            if stream_no % self.no_sec == 0:
+                if self.phase_locked:
+                    frames = self.eval_edges()
+                if len(frames) == 0:
+                    frames = [{}]
+                self.report_values(frames)
+                sweep = self.check_corr_quality()
+            mx = int(np.argmax(corr))
+            n = len(corr)
+            self.last = dict(mode='track', dumps=dumps, mx=mx,
+                             epl=np.array([corr[(mx - 1) % n], corr[mx],
+                                           corr[(mx + 1) % n]]),
+                             corr_mean=np.mean(corr), corr_std=np.std(corr),
+                             delay=delay, code_phase=code_phase, norm=norm,
+                             nps=len(self.prev_samples))
+            if sweep:
+                self.init_sweep()
+            else:
+                df, shift, self.phase_locked, _ = self.phase_locked_loop(dumps)
+                self.phase += shift
+                self.freq = self.confine(self.freq + df)
+                self.last.update(df=df, shift=shift)
+        return self.sweep, frames, code_phase, (self.corr_q, self.corr_l)
