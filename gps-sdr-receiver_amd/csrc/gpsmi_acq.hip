@@ -1,0 +1,299 @@
+// Acquisition: batched per-SV x Doppler parallel code-phase search on gfx950.
+//
+// Replaces the array arithmetic of reference src/gpsrecv.py:241-274.
+//
+//   acq_spectrum_kernel   one workgroup per Doppler bin: carrier wipe-off with
+//                         the reference's float32 phase argument
+//                         (gpsrecv.py:232-235), fold of the n_avg code periods
+//                         (sum of FFTs = FFT of the sum, :250-254), 2048-point
+//                         FFT in LDS, spectrum to a small L2-resident scratch.
+//   acq_corr_kernel       one workgroup per (SV, bin): conj(X) * R from
+//                         coalesced reads of the replica spectra, the same FFT
+//                         as the inverse (|ifft(Y)| = |fft(conj Y)| / N, :258),
+//                         |.|, then mean / population std / first-index argmax
+//                         (findCodePhase, :217-223) by wave64 shuffles.  The
+//                         nbins x nsv x 2048 correlation surface never reaches
+//                         HBM; 16 bytes per cell do.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "gpsmi_common.h"
+#include "gpsmi_fft.h"
+
+namespace gpsmi {
+
+// ---- wave / workgroup reductions (wave64) ---------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// larger value wins, ties go to the smaller index (np.argmax, first maximum)
+__device__ __forceinline__ void wave_argmax(float& v, int& i) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_down(v, o, 64);
+        int oi = __shfl_down(i, o, 64);
+        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+}
+
+// Statistics of the 2048 magnitudes held as mag[q] = |c[t + 256 q]|.
+// red: >= 16 floats of LDS scratch.  Result valid in every thread.
+__device__ __forceinline__ void corr_stats(const float* mag, int t, float* red,
+                                           int& amax, float& peak, float& mean, float& sd) {
+    const int wave = t >> 6, lane = t & 63;
+    float s = 0.f, bv = mag[0];
+    int bi = t;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        s += mag[q];
+        if (mag[q] > bv) { bv = mag[q]; bi = t + 256 * q; }   // ascending index: strict >
+    }
+    s = wave_sum(s);
+    wave_argmax(bv, bi);
+    __syncthreads();                       // red may still be read by an earlier call
+    if (lane == 0) { red[wave] = s; red[4 + wave] = bv; ((int*)red)[8 + wave] = bi; }
+    __syncthreads();
+    s = (red[0] + red[1]) + (red[2] + red[3]);
+    bv = red[4]; bi = ((int*)red)[8];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+        float ov = red[4 + w];
+        int oi = ((int*)red)[8 + w];
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    mean = s * (1.0f / kFftN);
+    float d2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { float d = mag[q] - mean; d2 += d * d; }
+    d2 = wave_sum(d2);
+    if (lane == 0) red[12 + wave] = d2;
+    __syncthreads();
+    d2 = (red[12] + red[13]) + (red[14] + red[15]);
+    sd = sqrtf(d2 * (1.0f / kFftN));
+    amax = bi;
+    peak = bv;
+}
+
+// ---- kernels ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void acq_spectrum_kernel(
+    const float2* __restrict__ iq, const float* __restrict__ t32,
+    const float* __restrict__ omega, int n_avg, float2* __restrict__ spectra,
+    const float2* __restrict__ tw) {
+    __shared__ float lds[kFftLdsFloats];
+    const int t = threadIdx.x, bin = blockIdx.x;
+    const float om = omega[bin];
+    float2 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = make_float2(0.f, 0.f);
+    for (int i = 0; i < n_avg; ++i) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            int k = i * kFftN + t + 256 * r;
+            float2 x = iq[k];
+            float p = __fmul_rn(om, t32[k]);      // float32 phase argument, phase0 = 0
+            float s, c;
+            sincosf(p, &s, &c);
+            // factor = (c, -s); factor * x as numpy multiplies complex64
+            v[r].x += c * x.x + s * x.y;
+            v[r].y += c * x.y - s * x.x;
+        }
+    }
+    fft2048(v, lds, tw, t);
+    const float sc = 1.0f / (float)n_avg;
+    float2* out = spectra + (size_t)bin * kFftN;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) out[t + 256 * q] = make_float2(v[q].x * sc, v[q].y * sc);
+}
+
+__global__ __launch_bounds__(256) void acq_corr_kernel(
+    const float2* __restrict__ spectra, const float2* __restrict__ rep,
+    const int* __restrict__ slot, gpsmi_peak* __restrict__ out, int nsv,
+    const float2* __restrict__ tw) {
+    __shared__ float lds[kFftLdsFloats];
+    __shared__ float red[16];
+    const int t = threadIdx.x, sv = blockIdx.x, bin = blockIdx.y;
+    const float2* X = spectra + (size_t)bin * kFftN;
+    const float2* R = rep + (size_t)slot[sv] * kFftN;
+    float2 v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        float2 x = X[t + 256 * q], r = R[t + 256 * q];
+        v[q] = make_float2(x.x * r.x + x.y * r.y, x.x * r.y - x.y * r.x);   // conj(x) * r
+    }
+    fft2048(v, lds, tw, t);
+    float mag[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) mag[q] = sqrtf(v[q].x * v[q].x + v[q].y * v[q].y) * (1.0f / kFftN);
+    int amax; float peak, mean, sd;
+    corr_stats(mag, t, red, amax, peak, mean, sd);
+    if (t == 0) {
+        // fft(conj Y)[n] = conj(N ifft(Y)[n]): same lag index, no reversal
+        gpsmi_peak p; p.argmax = amax; p.peak = peak; p.mean = mean; p.std = sd;
+        out[(size_t)bin * nsv + sv] = p;
+    }
+}
+
+}  // namespace gpsmi
+
+using namespace gpsmi;
+
+struct gpsmi_acq {
+    gpsmi_cfg cfg;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float2* d_tw = nullptr;
+    float* d_t32 = nullptr;
+    float2* d_rep = nullptr;          // [GPSMI_MAX_PRN + 1][cs]
+    bool have_rep[GPSMI_MAX_PRN + 1] = {};
+    float2* d_iq = nullptr;  size_t iq_cap = 0;
+    float2* d_spec = nullptr; size_t spec_cap = 0;   // bins
+    float* d_omega = nullptr; int* d_slot = nullptr; gpsmi_peak* d_peaks = nullptr;
+    size_t cell_cap = 0;
+    float last_ms = 0.f;
+};
+
+static int acq_reserve(gpsmi_acq* h, int nbins, int nsv) {
+    if ((size_t)nbins > h->spec_cap) {
+        if (h->d_spec) GPSMI_HIP(hipFree(h->d_spec));
+        if (h->d_omega) GPSMI_HIP(hipFree(h->d_omega));
+        h->d_spec = nullptr; h->d_omega = nullptr; h->spec_cap = 0;
+        GPSMI_HIP(hipMalloc((void**)&h->d_spec, (size_t)nbins * kFftN * sizeof(float2)));
+        GPSMI_HIP(hipMalloc((void**)&h->d_omega, (size_t)nbins * sizeof(float)));
+        h->spec_cap = nbins;
+    }
+    size_t cells = (size_t)nbins * nsv;
+    if (cells > h->cell_cap) {
+        if (h->d_peaks) GPSMI_HIP(hipFree(h->d_peaks));
+        h->d_peaks = nullptr; h->cell_cap = 0;
+        GPSMI_HIP(hipMalloc((void**)&h->d_peaks, cells * sizeof(gpsmi_peak)));
+        h->cell_cap = cells;
+    }
+    return GPSMI_OK;
+}
+
+extern "C" {
+
+int gpsmi_acq_create(const gpsmi_cfg* cfg, gpsmi_acq** out) {
+    GPSMI_REQUIRE(cfg && out, "null argument");
+    if (cfg->code_samples != kFftN)
+        return fail(GPSMI_E_UNSUPPORTED, "acquisition engine is built for code_samples = %d, got %d",
+                    kFftN, cfg->code_samples);
+    GPSMI_REQUIRE(cfg->n_cyc >= 1 && cfg->n_cyc <= 64, "n_cyc out of range");
+    GPSMI_HIP(hipSetDevice(cfg->device));
+    gpsmi_acq* h = new (std::nothrow) gpsmi_acq();
+    if (!h) return fail(GPSMI_E_NOMEM, "out of host memory");
+    h->cfg = *cfg;
+    *out = h;
+    GPSMI_HIP(hipStreamCreate(&h->stream));
+    GPSMI_HIP(hipEventCreate(&h->ev0));
+    GPSMI_HIP(hipEventCreate(&h->ev1));
+    std::vector<float2> tw;
+    make_twiddles(tw);
+    GPSMI_HIP(hipMalloc((void**)&h->d_tw, tw.size() * sizeof(float2)));
+    GPSMI_HIP(hipMemcpy(h->d_tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
+    // SEC_TIME (gpsrecv.py:32-33): float32(k+1) / SAMPLE_RATE in float32
+    const int ngps = cfg->n_cyc * cfg->code_samples;
+    const float fs = (float)(1000 * cfg->code_samples);
+    std::vector<float> t32(ngps);
+    for (int k = 0; k < ngps; ++k) t32[k] = (float)(k + 1) / fs;
+    GPSMI_HIP(hipMalloc((void**)&h->d_t32, ngps * sizeof(float)));
+    GPSMI_HIP(hipMemcpy(h->d_t32, t32.data(), ngps * sizeof(float), hipMemcpyHostToDevice));
+    GPSMI_HIP(hipMalloc((void**)&h->d_rep, (size_t)(GPSMI_MAX_PRN + 1) * kFftN * sizeof(float2)));
+    GPSMI_HIP(hipMalloc((void**)&h->d_slot, (GPSMI_MAX_PRN + 1) * sizeof(int)));
+    return GPSMI_OK;
+}
+
+int gpsmi_acq_destroy(gpsmi_acq* h) {
+    if (!h) return GPSMI_OK;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void* bufs[] = {h->d_tw, h->d_t32, h->d_rep, h->d_iq, h->d_spec, h->d_omega, h->d_slot,
+                    h->d_peaks};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return GPSMI_OK;
+}
+
+int gpsmi_acq_set_replica(gpsmi_acq* h, int prn, const float* spectrum) {
+    GPSMI_REQUIRE(h && spectrum, "null argument");
+    GPSMI_REQUIRE(prn >= 1 && prn <= GPSMI_MAX_PRN, "prn out of range 1..37");
+    GPSMI_HIP(hipSetDevice(h->cfg.device));
+    GPSMI_HIP(hipMemcpy(h->d_rep + (size_t)prn * kFftN, spectrum, kFftN * sizeof(float2),
+                        hipMemcpyHostToDevice));
+    h->have_rep[prn] = true;
+    return GPSMI_OK;
+}
+
+int gpsmi_acq_search_dev(gpsmi_acq* h, const void* d_iq, size_t n, const int32_t* prn, int nsv,
+                         const double* freqs, int nbins, int n_avg, gpsmi_peak* out,
+                         void* out_dev) {
+    GPSMI_REQUIRE(h && d_iq && prn && freqs, "null argument");
+    GPSMI_REQUIRE(out || out_dev, "no output requested");
+    GPSMI_REQUIRE(nsv >= 0 && nsv <= GPSMI_MAX_PRN, "nsv out of range");
+    GPSMI_REQUIRE(nbins >= 0 && nbins <= 65535, "nbins out of range");
+    GPSMI_REQUIRE(n_avg >= 1 && n_avg <= h->cfg.n_cyc, "n_avg out of range 1..n_cyc");
+    GPSMI_REQUIRE(n >= (size_t)n_avg * kFftN, "iq shorter than n_avg code periods");
+    for (int i = 0; i < nsv; ++i) {
+        GPSMI_REQUIRE(prn[i] >= 1 && prn[i] <= GPSMI_MAX_PRN, "prn out of range 1..37");
+        if (!h->have_rep[prn[i]])
+            return fail(GPSMI_E_STATE, "no replica set for PRN %d", (int)prn[i]);
+    }
+    h->last_ms = 0.f;
+    if (nsv == 0 || nbins == 0) return GPSMI_OK;            // empty search: nothing to do
+    GPSMI_HIP(hipSetDevice(h->cfg.device));
+    int rc = acq_reserve(h, nbins, nsv);
+    if (rc) return rc;
+    std::vector<float> om(nbins);
+    for (int b = 0; b < nbins; ++b) om[b] = (float)(2.0 * M_PI * freqs[b]);
+    GPSMI_HIP(hipMemcpyAsync(h->d_omega, om.data(), nbins * sizeof(float), hipMemcpyHostToDevice,
+                             h->stream));
+    GPSMI_HIP(hipMemcpyAsync(h->d_slot, prn, nsv * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    GPSMI_HIP(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(acq_spectrum_kernel, dim3(nbins), dim3(256), 0, h->stream,
+                       (const float2*)d_iq, h->d_t32, h->d_omega, n_avg, h->d_spec, h->d_tw);
+    hipLaunchKernelGGL(acq_corr_kernel, dim3(nsv, nbins), dim3(256), 0, h->stream, h->d_spec,
+                       h->d_rep, h->d_slot, h->d_peaks, nsv, h->d_tw);
+    GPSMI_HIP(hipGetLastError());
+    GPSMI_HIP(hipEventRecord(h->ev1, h->stream));
+    size_t bytes = (size_t)nbins * nsv * sizeof(gpsmi_peak);
+    if (out_dev)
+        GPSMI_HIP(hipMemcpyAsync(out_dev, h->d_peaks, bytes, hipMemcpyDeviceToDevice, h->stream));
+    if (out)
+        GPSMI_HIP(hipMemcpyAsync(out, h->d_peaks, bytes, hipMemcpyDeviceToHost, h->stream));
+    GPSMI_HIP(hipStreamSynchronize(h->stream));
+    GPSMI_HIP(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+    return GPSMI_OK;
+}
+
+int gpsmi_acq_search(gpsmi_acq* h, const float* iq, size_t n, const int32_t* prn, int nsv,
+                     const double* freqs, int nbins, int n_avg, gpsmi_peak* out) {
+    GPSMI_REQUIRE(h && iq && out, "null argument");
+    GPSMI_REQUIRE(n_avg >= 1 && n_avg <= h->cfg.n_cyc, "n_avg out of range 1..n_cyc");
+    GPSMI_REQUIRE(n >= (size_t)n_avg * kFftN, "iq shorter than n_avg code periods");
+    GPSMI_HIP(hipSetDevice(h->cfg.device));
+    size_t need = (size_t)n_avg * kFftN;
+    if (need > h->iq_cap) {
+        if (h->d_iq) GPSMI_HIP(hipFree(h->d_iq));
+        h->d_iq = nullptr; h->iq_cap = 0;
+        GPSMI_HIP(hipMalloc((void**)&h->d_iq, need * sizeof(float2)));
+        h->iq_cap = need;
+    }
+    GPSMI_HIP(hipMemcpyAsync(h->d_iq, iq, need * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+    return gpsmi_acq_search_dev(h, h->d_iq, need, prn, nsv, freqs, nbins, n_avg, out, nullptr);
+}
+
+int gpsmi_acq_last_ms(gpsmi_acq* h, float* ms) {
+    GPSMI_REQUIRE(h && ms, "null argument");
+    *ms = h->last_ms;
+    return GPSMI_OK;
+}
+
+}  // extern "C"

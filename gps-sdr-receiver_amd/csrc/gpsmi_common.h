@@ -1,0 +1,35 @@
+// Shared host-side helpers of libgpsmi: error reporting across the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <vector>
+
+#include "../../include/gpsmi.h"
+
+namespace gpsmi {
+
+// Text of the last failure on this thread (returned by gpsmi_last_error()).
+char* last_error_buf();
+int fail(int code, const char* fmt, ...);
+
+#define GPSMI_HIP(call)                                                          \
+    do {                                                                         \
+        hipError_t e__ = (call);                                                 \
+        if (e__ != hipSuccess)                                                   \
+            return ::gpsmi::fail(GPSMI_E_HIP, "%s: %s (%s:%d)", #call,           \
+                                 hipGetErrorString(e__), __FILE__, __LINE__);    \
+    } while (0)
+
+#define GPSMI_REQUIRE(cond, msg)                                                 \
+    do {                                                                         \
+        if (!(cond)) return ::gpsmi::fail(GPSMI_E_ARG, "%s: %s", __func__, msg); \
+    } while (0)
+
+// exp(-2 pi i k / 2048) computed in double, rounded once.
+void make_twiddles(std::vector<float2>& tw);
+
+inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+}  // namespace gpsmi

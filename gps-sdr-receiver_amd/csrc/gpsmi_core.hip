@@ -1,0 +1,131 @@
+// libgpsmi core: error text, device buffers, the u8-IQ unpack kernel.
+#include <cmath>
+#include <cstddef>
+#include <cstring>
+
+#include "gpsmi_common.h"
+
+namespace gpsmi {
+
+char* last_error_buf() {
+    static thread_local char buf[512] = "";
+    return buf;
+}
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(last_error_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+void make_twiddles(std::vector<float2>& tw) {
+    tw.resize(2048);
+    for (int k = 0; k < 2048; ++k) {
+        double a = -2.0 * M_PI * (double)k / 2048.0;
+        tw[k] = make_float2((float)cos(a), (float)sin(a));
+    }
+}
+
+// streamData's sample decode (reference src/gpsrecv.py:170-172):
+// raw = Q<<8 | I; sample = complex64(I + jQ)/127.5 - (1+1j).  numpy divides a
+// complex64 by the real scalar as (a + b*0) * fl32(1/127.5) (Smith's algorithm
+// with a zero imaginary divisor), i.e. a multiply by the rounded reciprocal:
+// bit-exact only when done the same way (tests/test_abi.py checks all 256).
+__global__ __launch_bounds__(256) void unpack_u8iq_kernel(float2* __restrict__ out,
+                                                          const uint16_t* __restrict__ raw,
+                                                          size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        unsigned v = raw[i];
+        const float scl = 1.0f / 127.5f;
+        float re = __fsub_rn(__fmul_rn((float)(v & 0xFF), scl), 1.0f);
+        float im = __fsub_rn(__fmul_rn((float)(v >> 8), scl), 1.0f);
+        out[i] = make_float2(re, im);
+    }
+}
+
+}  // namespace gpsmi
+
+using namespace gpsmi;
+
+extern "C" {
+
+const char* gpsmi_last_error(void) { return last_error_buf(); }
+const char* gpsmi_version(void) { return "gpsmi 0.1 (gfx950)"; }
+
+int gpsmi_abi_sizeof(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(gpsmi_cfg);
+        case 1: return (int)sizeof(gpsmi_peak);
+        case 2: return (int)sizeof(gpsmi_trk_state);
+        case 3: return (int)sizeof(gpsmi_trk_out);
+        case 4: return (int)offsetof(gpsmi_trk_out, code_phase);
+        default: return -1;
+    }
+}
+
+int gpsmi_device_count(int* n) {
+    GPSMI_REQUIRE(n, "null argument");
+    GPSMI_HIP(hipGetDeviceCount(n));
+    return GPSMI_OK;
+}
+
+int gpsmi_device_name(int device, char* buf, size_t len) {
+    GPSMI_REQUIRE(buf && len > 0, "null argument");
+    hipDeviceProp_t p;
+    GPSMI_HIP(hipGetDeviceProperties(&p, device));
+    snprintf(buf, len, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    return GPSMI_OK;
+}
+
+int gpsmi_dev_alloc(int device, size_t bytes, void** dptr) {
+    GPSMI_REQUIRE(dptr && bytes > 0, "null pointer or zero size");
+    GPSMI_HIP(hipSetDevice(device));
+    GPSMI_HIP(hipMalloc(dptr, bytes));
+    return GPSMI_OK;
+}
+
+int gpsmi_dev_free(int device, void* dptr) {
+    if (!dptr) return GPSMI_OK;
+    GPSMI_HIP(hipSetDevice(device));
+    GPSMI_HIP(hipFree(dptr));
+    return GPSMI_OK;
+}
+
+int gpsmi_dev_upload(int device, void* dptr, const void* host, size_t bytes) {
+    GPSMI_REQUIRE(dptr && host, "null pointer");
+    GPSMI_HIP(hipSetDevice(device));
+    GPSMI_HIP(hipMemcpy(dptr, host, bytes, hipMemcpyHostToDevice));
+    return GPSMI_OK;
+}
+
+int gpsmi_dev_download(int device, void* host, const void* dptr, size_t bytes) {
+    GPSMI_REQUIRE(dptr && host, "null pointer");
+    GPSMI_HIP(hipSetDevice(device));
+    GPSMI_HIP(hipMemcpy(host, dptr, bytes, hipMemcpyDeviceToHost));
+    return GPSMI_OK;
+}
+
+int gpsmi_dev_sync(int device) {
+    GPSMI_HIP(hipSetDevice(device));
+    GPSMI_HIP(hipDeviceSynchronize());
+    return GPSMI_OK;
+}
+
+int gpsmi_dev_unpack_u8iq(int device, void* d_iq, const void* d_raw, size_t n) {
+    GPSMI_REQUIRE(d_iq && d_raw, "null pointer");
+    if (n == 0) return GPSMI_OK;
+    GPSMI_HIP(hipSetDevice(device));
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(unpack_u8iq_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, (float2*)d_iq,
+                       (const uint16_t*)d_raw, n);
+    GPSMI_HIP(hipGetLastError());
+    GPSMI_HIP(hipDeviceSynchronize());
+    return GPSMI_OK;
+}
+
+}  // extern "C"

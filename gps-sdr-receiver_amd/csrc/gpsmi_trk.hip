@@ -1,0 +1,689 @@
+// Tracking: all channels of one device per call, closed loop or replay.
+//
+// Replaces the numeric part of gpslib.SatStream.process (reference
+// src/gpslib.py:1141-1210).  A "job" is one (channel, block) pair; the closed
+// loop runs the open channels of one block, replay runs nb x nch jobs at once
+// from a recorded state table.  Three kernels per call, in stream order:
+//
+//   trk_corr_kernel   one workgroup per job.  Carrier wipe-off of the centre
+//                     corr_avg code periods with the reference's float32 phase
+//                     argument (demodDoppler, :1343-1346), fold, 2048-point
+//                     FFT in LDS, x conj(replica spectrum), FFT again as the
+//                     inverse, |.|, mean / std / first argmax and the two
+//                     neighbours of the peak (cacodeCorr :1315-1327,
+//                     findCodePhase :1293-1304).  Thread 0 applies the
+//                     CORR_MIN threshold, fitCodePhase (:1268-1290) and picks
+//                     the DELAY the block is decoded with (:1181-1182).
+//   trk_dump_kernel   the correlator: one workgroup per (job, code period).
+//                     Carrier-NCO mix of the whole block times the replica
+//                     rolled by DELAY (decodeData :1400-1401), summed
+//                     separately before and after the code-period boundary so
+//                     that the epilogue can assemble the reference's windows
+//                     (:1408-1420), including the partial first window and the
+//                     carry into the next block (:1403-1405, :1440).
+//   trk_epilogue_kernel  one thread per job: prompt dumps (means), amplitude
+//                     statistics (:1186-1188), phaseLockedLoop (:1215-1262) and
+//                     the state update (:1178, :1205-1208).
+//
+// Loop-carried state lives in device memory; the closed loop needs no host
+// round trip between blocks.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "gpsmi_common.h"
+#include "gpsmi_fft.h"
+
+namespace gpsmi {
+
+constexpr float kTwoPiF = 6.28318530717958647692f;   // float32(2*pi), numpy's weak-scalar cast
+constexpr float kPiF = 3.14159265358979323846f;
+
+struct TrkParams {
+    int cs;            // code samples (2048)
+    int n_cyc;
+    int corr_avg;
+    float corr_min;
+    float min_freq, max_freq;
+    int nch;           // jobs per block
+    int df_no;         // 1024 / n_cyc
+    float t_last;      // SEC_TIME[NGPS-1]
+    float om_min, om_max;   // float32(2*pi*MIN_FREQ), float32(2*pi*MAX_FREQ) from float64
+};
+
+// per-job scratch between the kernels
+struct JobMid {
+    int delay_used;    // DELAY the block is decoded with
+    int active;
+};
+
+__device__ __forceinline__ float wave_sum_t(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ void wave_argmax_t(float& v, int& i) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_down(v, o, 64);
+        int oi = __shfl_down(i, o, 64);
+        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+}
+
+// omega as the reference forms 2*pi*freq for a float32 FREQ (numpy >= 2):
+// float32(2*pi) * freq in float32.
+__device__ __host__ __forceinline__ float omega_of(float freq) {
+#ifdef __HIP_DEVICE_COMPILE__
+    return __fmul_rn(kTwoPiF, freq);
+#else
+    volatile float w = kTwoPiF * freq;
+    return w;
+#endif
+}
+
+// carrier factor exp(-j(phase + omega t[k])) with the float32 phase argument
+__device__ __forceinline__ float2 wipe(float2 x, float phase, float om, float tk) {
+    float p = __fadd_rn(phase, __fmul_rn(om, tk));
+    float s, c;
+    sincosf(p, &s, &c);
+    return make_float2(c * x.x + s * x.y, c * x.y - s * x.x);
+}
+
+// fitCodePhase (gpslib.py:1268-1290) in double on the float32 correlation values
+__device__ inline double fit_code_phase(double lo, double pk, double hi, int mx) {
+    double tri = (lo > hi) ? 0.5 * (hi - lo) / (pk - hi) : 0.5 * (hi - lo) / (pk - lo);
+    double par = 0.5 * (hi - lo) / (2.0 * pk - hi - lo);
+    return (double)mx + 0.5 * (tri + par);
+}
+
+__global__ __launch_bounds__(256) void trk_corr_kernel(
+    const float2* __restrict__ iq, const gpsmi_trk_state* __restrict__ st_in,
+    const int* __restrict__ delay_forced, const float* __restrict__ t32,
+    const float2* __restrict__ rep, const float2* __restrict__ tw, TrkParams P,
+    gpsmi_trk_out* __restrict__ out, JobMid* __restrict__ mid) {
+    __shared__ float lds[kFftLdsFloats];
+    __shared__ float red[20];
+    const int t = threadIdx.x, job = blockIdx.x;
+    const gpsmi_trk_state& st = st_in[job];
+    if (st.prn <= 0) {
+        if (t == 0) { mid[job].active = 0; mid[job].delay_used = 0; out[job].prn = 0; }
+        return;
+    }
+    const float2* blk = iq + (size_t)(job / P.nch) * ((size_t)P.cs * P.n_cyc);
+    const float om = st.omega0 != 0.f ? st.omega0 : omega_of(st.freq);
+    const float ph = st.phase;
+    const int first = (P.n_cyc - P.corr_avg) / 2;
+    float2 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = make_float2(0.f, 0.f);
+    for (int i = first; i < first + P.corr_avg; ++i) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            int k = i * kFftN + t + 256 * r;
+            float2 w = wipe(blk[k], ph, om, t32[k]);
+            v[r].x += w.x; v[r].y += w.y;
+        }
+    }
+    fft2048(v, lds, tw, t);
+    const float sc = 1.0f / (float)P.corr_avg;
+    const float2* R = rep + (size_t)st.prn * kFftN;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        float2 x = make_float2(v[q].x * sc, v[q].y * sc), r = R[t + 256 * q];
+        v[q] = make_float2(x.x * r.x + x.y * r.y, x.x * r.y - x.y * r.x);   // conj(x) * r
+    }
+    __syncthreads();                     // LDS buffer 0 is rewritten by the next FFT
+    fft2048(v, lds, tw, t);
+    float mag[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) mag[q] = sqrtf(v[q].x * v[q].x + v[q].y * v[q].y) * (1.0f / kFftN);
+
+    // mean / std / first-index argmax
+    const int wave = t >> 6, lane = t & 63;
+    float s = 0.f, bv = mag[0];
+    int bi = t;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        s += mag[q];
+        if (mag[q] > bv) { bv = mag[q]; bi = t + 256 * q; }
+    }
+    s = wave_sum_t(s);
+    wave_argmax_t(bv, bi);
+    if (lane == 0) { red[wave] = s; red[4 + wave] = bv; ((int*)red)[8 + wave] = bi; }
+    __syncthreads();
+    s = (red[0] + red[1]) + (red[2] + red[3]);
+    bv = red[4]; bi = ((int*)red)[8];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+        float ov = red[4 + w];
+        int oi = ((int*)red)[8 + w];
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    const float mean = s * (1.0f / kFftN);
+    float d2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { float d = mag[q] - mean; d2 += d * d; }
+    d2 = wave_sum_t(d2);
+    if (lane == 0) red[12 + wave] = d2;
+    // neighbours of the peak, circular (fitCodePhase :1271-1272)
+    const int ia = (bi + kFftN - 1) & (kFftN - 1), ib = (bi + 1) & (kFftN - 1);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        if (t + 256 * q == ia) red[16] = mag[q];
+        if (t + 256 * q == ib) red[17] = mag[q];
+    }
+    __syncthreads();
+    if (t == 0) {
+        d2 = (red[12] + red[13]) + (red[14] + red[15]);
+        const float sd = sqrtf(d2 * (1.0f / kFftN));
+        const float norm = (bv - mean) / sd;
+        gpsmi_trk_out& o = out[job];
+        o.prn = st.prn;
+        o.mx = bi;
+        o.epl[0] = red[16]; o.epl[1] = bv; o.epl[2] = red[17];
+        o.corr_mean = mean; o.corr_std = sd;
+        o.norm_max_corr = norm;
+        int delay = -1;
+        double cp = -1.0;
+        if (norm > P.corr_min) {
+            delay = bi;
+            cp = fit_code_phase((double)red[16], (double)bv, (double)red[17], bi);
+        }
+        o.delay = delay;
+        o.code_phase = cp;
+        int used = delay >= 0 ? delay : st.delay;
+        if (delay_forced && delay_forced[job] >= 0) used = delay_forced[job];
+        o.delay_used = used;
+        mid[job].delay_used = used;
+        mid[job].active = 1;
+    }
+}
+
+// The correlator.  partial[job][i] = {sum over m < d, sum over m >= d} of
+// code[(m - d) mod cs] * wiped[i*cs + m], as two complex numbers.
+__global__ __launch_bounds__(256) void trk_dump_kernel(
+    const float2* __restrict__ iq, const gpsmi_trk_state* __restrict__ st_in,
+    const JobMid* __restrict__ mid, const float* __restrict__ t32,
+    const float* __restrict__ code, TrkParams P, float4* __restrict__ partial) {
+    __shared__ float red[16];
+    const int t = threadIdx.x, job = blockIdx.x, i = blockIdx.y;
+    if (!mid[job].active) return;
+    const gpsmi_trk_state& st = st_in[job];
+    const float2* blk = iq + (size_t)(job / P.nch) * ((size_t)P.cs * P.n_cyc);
+    const float om = st.omega0 != 0.f ? st.omega0 : omega_of(st.freq);
+    const float ph = st.phase;
+    const int d = mid[job].delay_used;
+    const float* c = code + (size_t)st.prn * kFftN;
+    float lo_r = 0.f, lo_i = 0.f, hi_r = 0.f, hi_i = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        int m = t + 256 * r;
+        int k = i * kFftN + m;
+        float2 w = wipe(blk[k], ph, om, t32[k]);
+        float cv = c[(m - d) & (kFftN - 1)];
+        float yr = cv * w.x, yi = cv * w.y;
+        if (m < d) { lo_r += yr; lo_i += yi; } else { hi_r += yr; hi_i += yi; }
+    }
+    lo_r = wave_sum_t(lo_r); lo_i = wave_sum_t(lo_i);
+    hi_r = wave_sum_t(hi_r); hi_i = wave_sum_t(hi_i);
+    const int wave = t >> 6, lane = t & 63;
+    if (lane == 0) {
+        red[wave] = lo_r; red[4 + wave] = lo_i; red[8 + wave] = hi_r; red[12 + wave] = hi_i;
+    }
+    __syncthreads();
+    if (t == 0) {
+        float4 p;
+        p.x = (red[0] + red[1]) + (red[2] + red[3]);
+        p.y = (red[4] + red[5]) + (red[6] + red[7]);
+        p.z = (red[8] + red[9]) + (red[10] + red[11]);
+        p.w = (red[12] + red[13]) + (red[14] + red[15]);
+        partial[(size_t)job * P.n_cyc + i] = p;
+    }
+}
+
+// np.mean of a float32 array of n <= 128 elements: numpy's pairwise kernel
+// (eight strided accumulators, tree-combined, tail added in order).
+__device__ inline float np_sum_f32(const float* a, int n) {
+    if (n < 8) {
+        float r = 0.f;
+        for (int i = 0; i < n; ++i) r = __fadd_rn(r, a[i]);
+        return r;
+    }
+    float r[8];
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; ++j) r[j] = __fadd_rn(r[j], a[i + j]);
+    float res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
+                          __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
+    for (; i < n; ++i) res = __fadd_rn(res, a[i]);
+    return res;
+}
+
+__global__ __launch_bounds__(64) void trk_epilogue_kernel(
+    const gpsmi_trk_state* __restrict__ st_in, gpsmi_trk_state* __restrict__ st_out,
+    const JobMid* __restrict__ mid, const float4* __restrict__ partial, TrkParams P,
+    int njobs, gpsmi_trk_out* __restrict__ out) {
+    const int job = blockIdx.x * blockDim.x + threadIdx.x;
+    if (job >= njobs) return;
+    if (!mid[job].active) {
+        if (st_out != st_in) st_out[job] = st_in[job];
+        return;
+    }
+    gpsmi_trk_state st = st_in[job];
+    gpsmi_trk_out& o = out[job];
+    const int d = mid[job].delay_used;
+    const int cs = P.cs, nc = P.n_cyc;
+    const float4* pp = partial + (size_t)job * nc;
+
+    // ---- prompt dumps: windows of decodeData (gpslib.py:1403-1420, :1440)
+    float gr[GPSMI_MAX_DUMPS], gi[GPSMI_MAX_DUMPS];
+    int nd = 0;
+    int n1 = st.nps + d;
+    float car_r = 0.f, car_i = 0.f;
+    int nps_new = 0;
+    if (n1 == 0) {
+        for (int i = 0; i < nc; ++i) {
+            gr[nd] = (pp[i].x + pp[i].z) / (float)cs;
+            gi[nd] = (pp[i].y + pp[i].w) / (float)cs;
+            ++nd;
+        }
+        o.first_len = cs;
+    } else {
+        gr[0] = (st.prev_sum_re + pp[0].x) / (float)n1;
+        gi[0] = (st.prev_sum_im + pp[0].y) / (float)n1;
+        nd = 1;
+        for (int j = 1; j < nc; ++j) {
+            gr[nd] = (pp[j - 1].z + pp[j].x) / (float)cs;
+            gi[nd] = (pp[j - 1].w + pp[j].y) / (float)cs;
+            ++nd;
+        }
+        if (d == 0) {                     // the last code period is complete
+            gr[nd] = pp[nc - 1].z / (float)cs;
+            gi[nd] = pp[nc - 1].w / (float)cs;
+            ++nd;
+        } else {                          // carried into the next block
+            car_r = pp[nc - 1].z; car_i = pp[nc - 1].w;
+            nps_new = cs - d;
+        }
+        o.first_len = n1;
+    }
+    o.n_dumps = nd;
+    for (int i = 0; i < GPSMI_MAX_DUMPS; ++i) {
+        o.dumps[2 * i] = i < nd ? gr[i] : 0.f;
+        o.dumps[2 * i + 1] = i < nd ? gi[i] : 0.f;
+    }
+
+    // ---- amplitude statistics (gpslib.py:1186-1187), float32 like numpy
+    float mag[GPSMI_MAX_DUMPS];
+    for (int i = 0; i < nd; ++i) mag[i] = hypotf(gr[i], gi[i]);
+    float mmean = np_sum_f32(mag, nd) / (float)nd;
+    float dev[GPSMI_MAX_DUMPS];
+    for (int i = 0; i < nd; ++i) { float e = __fsub_rn(mag[i], mmean); dev[i] = __fmul_rn(e, e); }
+    float sdev = sqrtf(np_sum_f32(dev, nd) / (float)nd);
+    o.std_dev = sdev;
+    o.amplitude = mmean / sdev;
+
+    // ---- phaseLockedLoop (gpslib.py:1215-1262)
+    float ph[GPSMI_MAX_DUMPS], real[GPSMI_MAX_DUMPS];
+    for (int i = 0; i < nd; ++i) ph[i] = atanf(gi[i] / gr[i]);
+    float dp = 0.f;
+    real[0] = ph[0];
+    for (int i = 1; i < nd; ++i) {
+        float delta = __fsub_rn(ph[i], ph[i - 1]);
+        if (fabsf(delta) > 2.0f) dp -= (delta > 0.f) ? 1.f : -1.f;
+        real[i] = __fadd_rn(ph[i], __fmul_rn(dp, kPiF));
+    }
+    const float offset = np_sum_f32(real + (nd - 4), 4) / 4.0f;
+    const float pdev = np_sum_f32(real, nd) / (float)nd;
+    const float max_df = 20.0f / (float)P.df_no;
+    int locked = st.phase_locked;
+    float df;
+    if (locked) {
+        float mean_df = np_sum_f32(st.df, st.df_len) / (float)st.df_len;
+        df = __fadd_rn(pdev, mean_df);                 // DF_GAIN2 = 1
+        if (fabsf(df) > max_df) df = (df > 0.f ? 1.f : -1.f) * max_df;
+        if (st.df_len >= P.df_no) {
+            for (int i = 1; i < st.df_len; ++i) st.df[i - 1] = st.df[i];
+            st.df_len -= 1;
+        }
+        st.df[st.df_len++] = df;
+    } else {
+        df = __fmul_rn(10.0f, pdev);                   // DF_GAIN1 = 10
+        st.df[0] = df;
+        st.df_len = 1;
+    }
+    if (fabsf(pdev) < 0.1f) locked = 1;
+
+    // ---- state update (gpslib.py:1178 via :1345-1346, then :1205-1208)
+    const float om = st.omega0 != 0.f ? st.omega0 : omega_of(st.freq);
+    float phase = __fadd_rn(st.phase, __fmul_rn(om, P.t_last));
+    float mod = fmodf(phase, kTwoPiF);                 // np.remainder(phase, 2*pi)
+    if (mod != 0.f && mod < 0.f) mod = __fadd_rn(mod, kTwoPiF);
+    phase = __fadd_rn(mod, offset);
+    float freq = __fadd_rn(st.freq, df);
+    float omega0 = 0.f;                                // FREQ is float32 from here on ...
+    if (freq > P.max_freq) { freq = P.max_freq; omega0 = P.om_max; }   // ... unless clamped to
+    else if (freq < P.min_freq) { freq = P.min_freq; omega0 = P.om_min; }  // a Python float
+
+    st.delay = d;
+    st.freq = freq;
+    st.omega0 = omega0;
+    st.phase = phase;
+    st.phase_locked = locked;
+    st.nps = nps_new;
+    st.prev_sum_re = car_r;
+    st.prev_sum_im = car_i;
+    st_out[job] = st;
+
+    o.df = df;
+    o.phase_shift = offset;
+    o.freq = freq;
+    o.phase = phase;
+    o.phase_locked = locked;
+    o.nps = nps_new;
+}
+
+}  // namespace gpsmi
+
+using namespace gpsmi;
+
+struct gpsmi_trk {
+    gpsmi_cfg cfg;
+    int max_ch = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    float2* d_tw = nullptr;
+    float* d_t32 = nullptr;
+    float2* d_rep = nullptr;         // [GPSMI_MAX_PRN + 1][cs] spectra
+    float* d_code = nullptr;         // [GPSMI_MAX_PRN + 1][cs] replica
+    bool have_rep[GPSMI_MAX_PRN + 1] = {};
+    float2* d_block = nullptr;       // staging for host blocks
+    // closed loop (max_ch jobs)
+    gpsmi_trk_state* d_state = nullptr;
+    std::vector<gpsmi_trk_state> h_state;
+    bool state_dirty_host = false;   // host copy newer than device
+    // job buffers, sized for njobs_cap
+    size_t njobs_cap = 0;
+    gpsmi_trk_state* d_tab_in = nullptr;
+    gpsmi_trk_state* d_tab_out = nullptr;
+    int* d_forced = nullptr;
+    JobMid* d_mid = nullptr;
+    float4* d_partial = nullptr;
+    gpsmi_trk_out* d_out = nullptr;
+    float last_total_ms = 0.f, last_corr_ms = 0.f;
+    TrkParams P;
+};
+
+static int trk_reserve(gpsmi_trk* h, size_t njobs) {
+    if (njobs <= h->njobs_cap) return GPSMI_OK;
+    void* olds[] = {h->d_tab_in, h->d_tab_out, h->d_forced, h->d_mid, h->d_partial, h->d_out};
+    for (void* p : olds)
+        if (p) GPSMI_HIP(hipFree(p));
+    h->d_tab_in = h->d_tab_out = nullptr; h->d_forced = nullptr; h->d_mid = nullptr;
+    h->d_partial = nullptr; h->d_out = nullptr; h->njobs_cap = 0;
+    GPSMI_HIP(hipMalloc((void**)&h->d_tab_in, njobs * sizeof(gpsmi_trk_state)));
+    GPSMI_HIP(hipMalloc((void**)&h->d_tab_out, njobs * sizeof(gpsmi_trk_state)));
+    GPSMI_HIP(hipMalloc((void**)&h->d_forced, njobs * sizeof(int)));
+    GPSMI_HIP(hipMalloc((void**)&h->d_mid, njobs * sizeof(JobMid)));
+    GPSMI_HIP(hipMalloc((void**)&h->d_partial, njobs * h->cfg.n_cyc * sizeof(float4)));
+    GPSMI_HIP(hipMalloc((void**)&h->d_out, njobs * sizeof(gpsmi_trk_out)));
+    h->njobs_cap = njobs;
+    return GPSMI_OK;
+}
+
+// the three kernels over njobs jobs on the handle's stream, events around them
+static int trk_launch(gpsmi_trk* h, const float2* d_iq, const gpsmi_trk_state* st_in,
+                      gpsmi_trk_state* st_out, const int* forced, int njobs, int nch) {
+    TrkParams P = h->P;
+    P.nch = nch;
+    GPSMI_HIP(hipEventRecord(h->ev[0], h->stream));
+    hipLaunchKernelGGL(trk_corr_kernel, dim3(njobs), dim3(256), 0, h->stream, d_iq, st_in, forced,
+                       h->d_t32, h->d_rep, h->d_tw, P, h->d_out, h->d_mid);
+    GPSMI_HIP(hipEventRecord(h->ev[1], h->stream));
+    hipLaunchKernelGGL(trk_dump_kernel, dim3(njobs, P.n_cyc), dim3(256), 0, h->stream, d_iq, st_in,
+                       h->d_mid, h->d_t32, h->d_code, P, h->d_partial);
+    GPSMI_HIP(hipEventRecord(h->ev[2], h->stream));
+    hipLaunchKernelGGL(trk_epilogue_kernel, dim3((njobs + 63) / 64), dim3(64), 0, h->stream, st_in,
+                       st_out, h->d_mid, h->d_partial, P, njobs, h->d_out);
+    GPSMI_HIP(hipGetLastError());
+    GPSMI_HIP(hipEventRecord(h->ev[3], h->stream));
+    return GPSMI_OK;
+}
+
+static int trk_push_state(gpsmi_trk* h) {
+    if (!h->state_dirty_host) return GPSMI_OK;
+    GPSMI_HIP(hipMemcpyAsync(h->d_state, h->h_state.data(), h->max_ch * sizeof(gpsmi_trk_state),
+                             hipMemcpyHostToDevice, h->stream));
+    GPSMI_HIP(hipStreamSynchronize(h->stream));
+    h->state_dirty_host = false;
+    return GPSMI_OK;
+}
+
+static int trk_pull_state(gpsmi_trk* h) {
+    if (h->state_dirty_host) return GPSMI_OK;        // host copy is the newest
+    GPSMI_HIP(hipMemcpyAsync(h->h_state.data(), h->d_state, h->max_ch * sizeof(gpsmi_trk_state),
+                             hipMemcpyDeviceToHost, h->stream));
+    GPSMI_HIP(hipStreamSynchronize(h->stream));
+    return GPSMI_OK;
+}
+
+extern "C" {
+
+int gpsmi_trk_create(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk** out) {
+    GPSMI_REQUIRE(cfg && out, "null argument");
+    GPSMI_REQUIRE(max_ch >= 1 && max_ch <= 4096, "max_ch out of range");
+    if (cfg->code_samples != kFftN)
+        return fail(GPSMI_E_UNSUPPORTED, "tracking engine is built for code_samples = %d, got %d",
+                    kFftN, cfg->code_samples);
+    GPSMI_REQUIRE(cfg->n_cyc >= 4 && cfg->n_cyc + 1 <= GPSMI_MAX_DUMPS, "n_cyc out of range 4..32");
+    GPSMI_REQUIRE(cfg->corr_avg >= 1, "corr_avg must be >= 1");
+    GPSMI_REQUIRE(1024 / cfg->n_cyc <= GPSMI_MAX_DF, "n_cyc too small for the DF list");
+    GPSMI_HIP(hipSetDevice(cfg->device));
+    gpsmi_trk* h = new (std::nothrow) gpsmi_trk();
+    if (!h) return fail(GPSMI_E_NOMEM, "out of host memory");
+    h->cfg = *cfg;
+    h->max_ch = max_ch;
+    *out = h;
+    GPSMI_HIP(hipStreamCreate(&h->stream));
+    for (auto& e : h->ev) GPSMI_HIP(hipEventCreate(&e));
+    std::vector<float2> tw;
+    make_twiddles(tw);
+    GPSMI_HIP(hipMalloc((void**)&h->d_tw, tw.size() * sizeof(float2)));
+    GPSMI_HIP(hipMemcpy(h->d_tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
+    const int ngps = cfg->n_cyc * cfg->code_samples;
+    const float fs = (float)(1000 * cfg->code_samples);
+    std::vector<float> t32(ngps);
+    for (int k = 0; k < ngps; ++k) t32[k] = (float)(k + 1) / fs;   // gpslib.py:1053-1054
+    GPSMI_HIP(hipMalloc((void**)&h->d_t32, ngps * sizeof(float)));
+    GPSMI_HIP(hipMemcpy(h->d_t32, t32.data(), ngps * sizeof(float), hipMemcpyHostToDevice));
+    GPSMI_HIP(hipMalloc((void**)&h->d_rep, (size_t)(GPSMI_MAX_PRN + 1) * kFftN * sizeof(float2)));
+    GPSMI_HIP(hipMalloc((void**)&h->d_code, (size_t)(GPSMI_MAX_PRN + 1) * kFftN * sizeof(float)));
+    GPSMI_HIP(hipMalloc((void**)&h->d_block, (size_t)ngps * sizeof(float2)));
+    GPSMI_HIP(hipMalloc((void**)&h->d_state, max_ch * sizeof(gpsmi_trk_state)));
+    h->h_state.assign(max_ch, gpsmi_trk_state{});
+    GPSMI_HIP(hipMemset(h->d_state, 0, max_ch * sizeof(gpsmi_trk_state)));
+    TrkParams& P = h->P;
+    P.cs = cfg->code_samples; P.n_cyc = cfg->n_cyc;
+    P.corr_avg = cfg->corr_avg < cfg->n_cyc ? cfg->corr_avg : cfg->n_cyc;   // gpslib.py:1071
+    P.corr_min = cfg->corr_min; P.min_freq = cfg->min_freq; P.max_freq = cfg->max_freq;
+    P.nch = max_ch; P.df_no = 1024 / cfg->n_cyc; P.t_last = t32[ngps - 1];
+    P.om_min = (float)(2.0 * M_PI * (double)cfg->min_freq);
+    P.om_max = (float)(2.0 * M_PI * (double)cfg->max_freq);
+    return trk_reserve(h, max_ch);
+}
+
+int gpsmi_trk_destroy(gpsmi_trk* h) {
+    if (!h) return GPSMI_OK;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void* bufs[] = {h->d_tw, h->d_t32, h->d_rep, h->d_code, h->d_block, h->d_state, h->d_tab_in,
+                    h->d_tab_out, h->d_forced, h->d_mid, h->d_partial, h->d_out};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    for (auto e : h->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return GPSMI_OK;
+}
+
+int gpsmi_trk_set_replica(gpsmi_trk* h, int prn, const float* replica, const float* spectrum) {
+    GPSMI_REQUIRE(h && replica && spectrum, "null argument");
+    GPSMI_REQUIRE(prn >= 1 && prn <= GPSMI_MAX_PRN, "prn out of range 1..37");
+    GPSMI_HIP(hipSetDevice(h->cfg.device));
+    GPSMI_HIP(hipMemcpy(h->d_code + (size_t)prn * kFftN, replica, kFftN * sizeof(float),
+                        hipMemcpyHostToDevice));
+    GPSMI_HIP(hipMemcpy(h->d_rep + (size_t)prn * kFftN, spectrum, kFftN * sizeof(float2),
+                        hipMemcpyHostToDevice));
+    h->have_rep[prn] = true;
+    return GPSMI_OK;
+}
+
+int gpsmi_trk_open(gpsmi_trk* h, int ch, int prn, float freq_hz, int delay) {
+    GPSMI_REQUIRE(h, "null handle");
+    GPSMI_REQUIRE(ch >= 0 && ch < h->max_ch, "channel out of range");
+    GPSMI_REQUIRE(prn >= 1 && prn <= GPSMI_MAX_PRN, "prn out of range 1..37");
+    GPSMI_REQUIRE(delay >= 0 && delay < h->cfg.code_samples, "delay out of range");
+    if (!h->have_rep[prn]) return fail(GPSMI_E_STATE, "no replica set for PRN %d", prn);
+    GPSMI_HIP(hipSetDevice(h->cfg.device));
+    int rc = trk_pull_state(h);
+    if (rc) return rc;
+    gpsmi_trk_state st{};                 // SatStream.__init__ (gpslib.py:1050-1091)
+    st.prn = prn; st.delay = delay; st.freq = freq_hz; st.phase = 0.f;
+    st.omega0 = (float)(2.0 * M_PI * (double)freq_hz);    // FREQ is a Python float here
+    st.df_len = 1; st.df[0] = 0.f;
+    h->h_state[ch] = st;
+    h->state_dirty_host = true;
+    return GPSMI_OK;
+}
+
+int gpsmi_trk_close(gpsmi_trk* h, int ch) {
+    GPSMI_REQUIRE(h, "null handle");
+    GPSMI_REQUIRE(ch >= 0 && ch < h->max_ch, "channel out of range");
+    GPSMI_HIP(hipSetDevice(h->cfg.device));
+    int rc = trk_pull_state(h);
+    if (rc) return rc;
+    if (h->h_state[ch].prn == 0) return fail(GPSMI_E_STATE, "channel %d is not open", ch);
+    h->h_state[ch] = gpsmi_trk_state{};
+    h->state_dirty_host = true;
+    return GPSMI_OK;
+}
+
+int gpsmi_trk_get_state(gpsmi_trk* h, int ch, gpsmi_trk_state* st) {
+    GPSMI_REQUIRE(h && st, "null argument");
+    GPSMI_REQUIRE(ch >= 0 && ch < h->max_ch, "channel out of range");
+    GPSMI_HIP(hipSetDevice(h->cfg.device));
+    int rc = trk_pull_state(h);
+    if (rc) return rc;
+    *st = h->h_state[ch];
+    return GPSMI_OK;
+}
+
+int gpsmi_trk_set_state(gpsmi_trk* h, int ch, const gpsmi_trk_state* st) {
+    GPSMI_REQUIRE(h && st, "null argument");
+    GPSMI_REQUIRE(ch >= 0 && ch < h->max_ch, "channel out of range");
+    GPSMI_REQUIRE(st->prn >= 0 && st->prn <= GPSMI_MAX_PRN, "prn out of range");
+    GPSMI_REQUIRE(st->delay >= 0 && st->delay < h->cfg.code_samples, "delay out of range");
+    GPSMI_REQUIRE(st->nps >= 0 && st->nps <= h->cfg.code_samples, "nps out of range");
+    GPSMI_REQUIRE(st->df_len >= 1 && st->df_len <= h->P.df_no, "df_len out of range");
+    if (st->prn && !h->have_rep[st->prn])
+        return fail(GPSMI_E_STATE, "no replica set for PRN %d", st->prn);
+    GPSMI_HIP(hipSetDevice(h->cfg.device));
+    int rc = trk_pull_state(h);
+    if (rc) return rc;
+    h->h_state[ch] = *st;
+    h->state_dirty_host = true;
+    return GPSMI_OK;
+}
+
+int gpsmi_trk_erase_prev(gpsmi_trk* h, int ch) {
+    GPSMI_REQUIRE(h, "null handle");
+    GPSMI_REQUIRE(ch >= 0 && ch < h->max_ch, "channel out of range");
+    GPSMI_HIP(hipSetDevice(h->cfg.device));
+    int rc = trk_pull_state(h);
+    if (rc) return rc;
+    h->h_state[ch].nps = 0;               // PREV_SAMPLES = [] (gpslib.py:1095-1099)
+    h->h_state[ch].prev_sum_re = h->h_state[ch].prev_sum_im = 0.f;
+    h->state_dirty_host = true;
+    return GPSMI_OK;
+}
+
+int gpsmi_trk_process_dev(gpsmi_trk* h, const void* d_iq, size_t n, gpsmi_trk_out* out) {
+    GPSMI_REQUIRE(h && d_iq, "null argument");
+    GPSMI_REQUIRE(n == (size_t)h->cfg.n_cyc * h->cfg.code_samples, "block must hold NGPS samples");
+    GPSMI_HIP(hipSetDevice(h->cfg.device));
+    int rc = trk_push_state(h);
+    if (rc) return rc;
+    rc = trk_launch(h, (const float2*)d_iq, h->d_state, h->d_state, nullptr, h->max_ch, h->max_ch);
+    if (rc) return rc;
+    if (out)
+        GPSMI_HIP(hipMemcpyAsync(out, h->d_out, h->max_ch * sizeof(gpsmi_trk_out),
+                                 hipMemcpyDeviceToHost, h->stream));
+    GPSMI_HIP(hipStreamSynchronize(h->stream));
+    GPSMI_HIP(hipEventElapsedTime(&h->last_total_ms, h->ev[0], h->ev[3]));
+    GPSMI_HIP(hipEventElapsedTime(&h->last_corr_ms, h->ev[1], h->ev[2]));
+    return GPSMI_OK;
+}
+
+int gpsmi_trk_process(gpsmi_trk* h, const float* iq, size_t n, gpsmi_trk_out* out) {
+    GPSMI_REQUIRE(h && iq && out, "null argument");
+    GPSMI_REQUIRE(n == (size_t)h->cfg.n_cyc * h->cfg.code_samples, "block must hold NGPS samples");
+    GPSMI_HIP(hipSetDevice(h->cfg.device));
+    GPSMI_HIP(hipMemcpyAsync(h->d_block, iq, n * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+    return gpsmi_trk_process_dev(h, h->d_block, n, out);
+}
+
+int gpsmi_trk_replay(gpsmi_trk* h, const void* d_iq, int nb, const gpsmi_trk_state* table,
+                     const int32_t* delay_used, gpsmi_trk_out* out) {
+    GPSMI_REQUIRE(h && d_iq && table && out, "null argument");
+    GPSMI_REQUIRE(nb >= 0, "negative block count");
+    if (nb == 0) return GPSMI_OK;
+    GPSMI_HIP(hipSetDevice(h->cfg.device));
+    const int nch = h->max_ch;
+    const size_t njobs = (size_t)nb * nch;
+    for (size_t j = 0; j < njobs; ++j) {
+        const gpsmi_trk_state& s = table[j];
+        if (s.prn < 0 || s.prn > GPSMI_MAX_PRN || (s.prn && !h->have_rep[s.prn]))
+            return fail(GPSMI_E_ARG, "replay table row %zu: bad PRN %d", j, s.prn);
+        if (s.prn && (s.delay < 0 || s.delay >= h->cfg.code_samples || s.nps < 0 ||
+                      s.nps > h->cfg.code_samples || s.df_len < 1 || s.df_len > h->P.df_no))
+            return fail(GPSMI_E_ARG, "replay table row %zu: state out of range", j);
+        if (delay_used && delay_used[j] >= h->cfg.code_samples)
+            return fail(GPSMI_E_ARG, "replay table row %zu: delay_used out of range", j);
+    }
+    int rc = trk_reserve(h, njobs);
+    if (rc) return rc;
+    GPSMI_HIP(hipMemcpyAsync(h->d_tab_in, table, njobs * sizeof(gpsmi_trk_state),
+                             hipMemcpyHostToDevice, h->stream));
+    if (delay_used)
+        GPSMI_HIP(hipMemcpyAsync(h->d_forced, delay_used, njobs * sizeof(int),
+                                 hipMemcpyHostToDevice, h->stream));
+    rc = trk_launch(h, (const float2*)d_iq, h->d_tab_in, h->d_tab_out,
+                    delay_used ? h->d_forced : nullptr, (int)njobs, nch);
+    if (rc) return rc;
+    GPSMI_HIP(hipMemcpyAsync(out, h->d_out, njobs * sizeof(gpsmi_trk_out), hipMemcpyDeviceToHost,
+                             h->stream));
+    GPSMI_HIP(hipStreamSynchronize(h->stream));
+    GPSMI_HIP(hipEventElapsedTime(&h->last_total_ms, h->ev[0], h->ev[3]));
+    GPSMI_HIP(hipEventElapsedTime(&h->last_corr_ms, h->ev[1], h->ev[2]));
+    return GPSMI_OK;
+}
+
+int gpsmi_trk_replay_states(gpsmi_trk* h, gpsmi_trk_state* states, size_t n) {
+    GPSMI_REQUIRE(h && states, "null argument");
+    GPSMI_REQUIRE(n <= h->njobs_cap, "more states requested than the last replay produced");
+    GPSMI_HIP(hipSetDevice(h->cfg.device));
+    GPSMI_HIP(hipMemcpy(states, h->d_tab_out, n * sizeof(gpsmi_trk_state), hipMemcpyDeviceToHost));
+    return GPSMI_OK;
+}
+
+int gpsmi_trk_last_ms(gpsmi_trk* h, float* total_ms, float* correlator_ms) {
+    GPSMI_REQUIRE(h, "null handle");
+    if (total_ms) *total_ms = h->last_total_ms;
+    if (correlator_ms) *correlator_ms = h->last_corr_ms;
+    return GPSMI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,152 @@
+"""ctypes binding of libgpsmi.so (declarations mirror include/gpsmi.h).
+
+There is no fallback of any kind: if the shared library is missing or a call
+fails, ``EngineError`` is raised.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+MAX_PRN = 37
+MAX_DUMPS = 33
+MAX_DF = 128
+COMM_ID_BYTES = 128
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libgpsmi.so')
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class Cfg(C.Structure):
+    _fields_ = [('code_samples', C.c_int32), ('n_cyc', C.c_int32),
+                ('corr_avg', C.c_int32), ('sweep_corr_avg', C.c_int32),
+                ('corr_min', C.c_float), ('min_freq', C.c_float),
+                ('max_freq', C.c_float), ('device', C.c_int32)]
+
+
+# numpy views of the C structs (same layout; checked against ctypes below)
+PEAK_DTYPE = np.dtype([('argmax', np.int32), ('peak', np.float32),
+                       ('mean', np.float32), ('std', np.float32)])
+
+STATE_DTYPE = np.dtype([
+    ('prn', np.int32), ('delay', np.int32), ('freq', np.float32),
+    ('phase', np.float32), ('phase_locked', np.int32), ('nps', np.int32),
+    ('prev_sum_re', np.float32), ('prev_sum_im', np.float32),
+    ('df_len', np.int32), ('omega0', np.float32),
+    ('df', np.float32, (MAX_DF,))])
+
+OUT_DTYPE = np.dtype([
+    ('prn', np.int32), ('n_dumps', np.int32),
+    ('dumps', np.float32, (2 * MAX_DUMPS,)),
+    ('first_len', np.int32), ('mx', np.int32), ('epl', np.float32, (3,)),
+    ('corr_mean', np.float32), ('corr_std', np.float32),
+    ('norm_max_corr', np.float32), ('delay', np.int32),
+    ('code_phase', np.float64), ('delay_used', np.int32),
+    ('std_dev', np.float32), ('amplitude', np.float32), ('df', np.float32),
+    ('phase_shift', np.float32), ('freq', np.float32), ('phase', np.float32),
+    ('phase_locked', np.int32), ('nps', np.int32)], align=True)
+
+EXPORTS = [
+    'gpsmi_last_error', 'gpsmi_version', 'gpsmi_abi_sizeof',
+    'gpsmi_device_count',
+    'gpsmi_device_name', 'gpsmi_dev_alloc', 'gpsmi_dev_free',
+    'gpsmi_dev_upload', 'gpsmi_dev_download', 'gpsmi_dev_sync',
+    'gpsmi_dev_unpack_u8iq',
+    'gpsmi_acq_create', 'gpsmi_acq_destroy', 'gpsmi_acq_set_replica',
+    'gpsmi_acq_search', 'gpsmi_acq_search_dev', 'gpsmi_acq_last_ms',
+    'gpsmi_trk_create', 'gpsmi_trk_destroy', 'gpsmi_trk_set_replica',
+    'gpsmi_trk_open', 'gpsmi_trk_close', 'gpsmi_trk_get_state',
+    'gpsmi_trk_set_state', 'gpsmi_trk_erase_prev', 'gpsmi_trk_process',
+    'gpsmi_trk_process_dev', 'gpsmi_trk_replay', 'gpsmi_trk_replay_states',
+    'gpsmi_trk_last_ms',
+    'gpsmi_comm_unique_id', 'gpsmi_comm_create', 'gpsmi_comm_destroy',
+    'gpsmi_comm_allgather_peaks',
+]
+
+_lib = None
+
+
+def load():
+    """Load libgpsmi.so once; raise EngineError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineError(
+            f'{LIB_PATH} not found: build it with `make -C gps-sdr-receiver_amd` '
+            '(or `python -c "import __graft_entry__ as g; g.build()"`); '
+            'gpsmi has no CPU fallback')
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise EngineError(f'cannot load {LIB_PATH}: {e}') from e
+    vp, i32, f32, sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
+    P = C.POINTER
+    lib.gpsmi_last_error.restype = C.c_char_p
+    lib.gpsmi_version.restype = C.c_char_p
+    sig = {
+        'gpsmi_abi_sizeof': [C.c_int],
+        'gpsmi_device_count': [P(C.c_int)],
+        'gpsmi_device_name': [C.c_int, C.c_char_p, sz],
+        'gpsmi_dev_alloc': [C.c_int, sz, P(vp)],
+        'gpsmi_dev_free': [C.c_int, vp],
+        'gpsmi_dev_upload': [C.c_int, vp, vp, sz],
+        'gpsmi_dev_download': [C.c_int, vp, vp, sz],
+        'gpsmi_dev_sync': [C.c_int],
+        'gpsmi_dev_unpack_u8iq': [C.c_int, vp, vp, sz],
+        'gpsmi_acq_create': [P(Cfg), P(vp)],
+        'gpsmi_acq_destroy': [vp],
+        'gpsmi_acq_set_replica': [vp, C.c_int, vp],
+        'gpsmi_acq_search': [vp, vp, sz, vp, C.c_int, vp, C.c_int, C.c_int, vp],
+        'gpsmi_acq_search_dev': [vp, vp, sz, vp, C.c_int, vp, C.c_int, C.c_int,
+                                 vp, vp],
+        'gpsmi_acq_last_ms': [vp, P(f32)],
+        'gpsmi_trk_create': [P(Cfg), C.c_int, P(vp)],
+        'gpsmi_trk_destroy': [vp],
+        'gpsmi_trk_set_replica': [vp, C.c_int, vp, vp],
+        'gpsmi_trk_open': [vp, C.c_int, C.c_int, f32, C.c_int],
+        'gpsmi_trk_close': [vp, C.c_int],
+        'gpsmi_trk_get_state': [vp, C.c_int, vp],
+        'gpsmi_trk_set_state': [vp, C.c_int, vp],
+        'gpsmi_trk_erase_prev': [vp, C.c_int],
+        'gpsmi_trk_process': [vp, vp, sz, vp],
+        'gpsmi_trk_process_dev': [vp, vp, sz, vp],
+        'gpsmi_trk_replay': [vp, vp, C.c_int, vp, vp, vp],
+        'gpsmi_trk_replay_states': [vp, vp, sz],
+        'gpsmi_trk_last_ms': [vp, P(f32), P(f32)],
+        'gpsmi_comm_unique_id': [vp],
+        'gpsmi_comm_create': [vp, C.c_int, C.c_int, C.c_int, P(vp)],
+        'gpsmi_comm_destroy': [vp],
+        'gpsmi_comm_allgather_peaks': [vp, vp, vp, C.c_int, vp],
+    }
+    for name, args in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    want = [C.sizeof(Cfg), PEAK_DTYPE.itemsize, STATE_DTYPE.itemsize,
+            OUT_DTYPE.itemsize, OUT_DTYPE.fields['code_phase'][1]]
+    got = [lib.gpsmi_abi_sizeof(i) for i in range(5)]
+    if want != got:
+        raise EngineError(f'ABI mismatch between gpsmi/_lib.py {want} and '
+                          f'libgpsmi.so {got}')
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().gpsmi_last_error().decode(errors='replace')
+        raise EngineError(f'{what} failed ({rc}): {msg}')
+
+
+def ptr(a):
+    """void* of a C-contiguous numpy array (or None)."""
+    if a is None:
+        return None
+    if not a.flags['C_CONTIGUOUS']:
+        raise ValueError('array must be C-contiguous')
+    return a.ctypes.data_as(C.c_void_p)

@@ -1,0 +1,268 @@
+"""Thin Python objects over the C ABI: device buffers, the acquisition engine and
+the tracking engine.  All arithmetic happens in libgpsmi.so on the GPU; these
+classes only marshal numpy arrays and keep handles alive."""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib, codes
+from ._lib import (EngineError, OUT_DTYPE, PEAK_DTYPE, STATE_DTYPE, check,  # noqa: F401
+                   ptr)
+
+
+@dataclass
+class Config:
+    """The gpsglob.py constants the path depends on (reference
+    src/gpsglob.py:35-131)."""
+    code_samples: int = 2048
+    n_cyc: int = 32
+    corr_avg: int = 8
+    sweep_corr_avg: int = 4
+    corr_min: float = 8.0
+    min_freq: float = -5000.0
+    max_freq: float = 5000.0
+    step_freq: float = 200
+    it_sweep: int = 40
+    it_sweep_all: int = 10
+    max_sat: int = 11
+    device: int = 0
+
+    @property
+    def ngps(self):
+        return self.code_samples * self.n_cyc
+
+    @property
+    def sample_rate(self):
+        return 1000 * self.code_samples
+
+    def c_struct(self):
+        return _lib.Cfg(self.code_samples, self.n_cyc, self.corr_avg,
+                        self.sweep_corr_avg, self.corr_min, self.min_freq,
+                        self.max_freq, self.device)
+
+
+def device_count():
+    n = C.c_int(0)
+    check(_lib.load().gpsmi_device_count(C.byref(n)), 'gpsmi_device_count')
+    return n.value
+
+
+def device_name(device=0):
+    buf = C.create_string_buffer(256)
+    check(_lib.load().gpsmi_device_name(device, buf, 256), 'gpsmi_device_name')
+    return buf.value.decode()
+
+
+class DeviceBuffer:
+    """A block of HBM owned by Python (IQ kept resident between calls)."""
+
+    def __init__(self, nbytes, device=0):
+        self.lib = _lib.load()
+        self.device = device
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(self.lib.gpsmi_dev_alloc(device, self.nbytes, C.byref(p)),
+              'gpsmi_dev_alloc')
+        self.ptr = p
+
+    def upload(self, arr, offset=0):
+        arr = np.ascontiguousarray(arr)
+        if offset + arr.nbytes > self.nbytes:
+            raise ValueError('upload exceeds the buffer')
+        dst = C.c_void_p(self.ptr.value + offset)
+        check(self.lib.gpsmi_dev_upload(self.device, dst, ptr(arr), arr.nbytes),
+              'gpsmi_dev_upload')
+
+    def download(self, dtype, count, offset=0):
+        out = np.empty(count, dtype=dtype)
+        if offset + out.nbytes > self.nbytes:
+            raise ValueError('download exceeds the buffer')
+        src = C.c_void_p(self.ptr.value + offset)
+        check(self.lib.gpsmi_dev_download(self.device, ptr(out), src,
+                                          out.nbytes), 'gpsmi_dev_download')
+        return out
+
+    def at(self, offset):
+        return C.c_void_p(self.ptr.value + int(offset))
+
+    def free(self):
+        if self.ptr:
+            check(self.lib.gpsmi_dev_free(self.device, self.ptr),
+                  'gpsmi_dev_free')
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def unpack_u8iq(d_out, d_raw, n, device=0):
+    """raw uint16 (Q<<8|I) -> complex64 on the device (gpsrecv.py:170-172)."""
+    check(_lib.load().gpsmi_dev_unpack_u8iq(device, d_out, d_raw, n),
+          'gpsmi_dev_unpack_u8iq')
+
+
+def sync(device=0):
+    check(_lib.load().gpsmi_dev_sync(device), 'gpsmi_dev_sync')
+
+
+def _spectrum_c64(prn, cs):
+    return np.ascontiguousarray(codes.replica_spectrum(prn, cs)
+                                .astype(np.complex64))
+
+
+class AcqEngine:
+    """Search surface of gpsrecv.sweepAllSats (reference gpsrecv.py:241-274)."""
+
+    def __init__(self, cfg=None, prns=range(1, 33)):
+        self.cfg = cfg or Config()
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        cs = self.cfg.c_struct()
+        check(self.lib.gpsmi_acq_create(C.byref(cs), C.byref(h)),
+              'gpsmi_acq_create')
+        self.h = h
+        for p in prns:
+            spec = _spectrum_c64(p, self.cfg.code_samples)
+            check(self.lib.gpsmi_acq_set_replica(self.h, p, ptr(spec)),
+                  'gpsmi_acq_set_replica')
+
+    def search(self, iq, prns, freqs, n_avg, out_dev=None):
+        """iq: complex64 numpy array (host) or a (c_void_p, n) device pair.
+        Returns a structured array [nbins, nsv] of (argmax, peak, mean, std)."""
+        prn_a = np.ascontiguousarray(prns, dtype=np.int32)
+        f_a = np.ascontiguousarray(freqs, dtype=np.float64)
+        out = np.zeros((len(f_a), len(prn_a)), dtype=PEAK_DTYPE)
+        if isinstance(iq, tuple):
+            d_iq, n = iq
+            check(self.lib.gpsmi_acq_search_dev(
+                self.h, d_iq, n, ptr(prn_a), len(prn_a), ptr(f_a), len(f_a),
+                n_avg, ptr(out), out_dev), 'gpsmi_acq_search_dev')
+        else:
+            iq = np.ascontiguousarray(iq, dtype=np.complex64)
+            check(self.lib.gpsmi_acq_search(
+                self.h, ptr(iq), iq.size, ptr(prn_a), len(prn_a), ptr(f_a),
+                len(f_a), n_avg, ptr(out)), 'gpsmi_acq_search')
+        return out
+
+    def last_ms(self):
+        ms = C.c_float(0)
+        check(self.lib.gpsmi_acq_last_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if self.h:
+            self.lib.gpsmi_acq_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class TrkEngine:
+    """All tracking channels of one GPU (numeric part of SatStream.process,
+    reference gpslib.py:1141-1210)."""
+
+    def __init__(self, cfg=None, max_ch=12, prns=range(1, 33)):
+        self.cfg = cfg or Config()
+        self.max_ch = max_ch
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        cs = self.cfg.c_struct()
+        check(self.lib.gpsmi_trk_create(C.byref(cs), max_ch, C.byref(h)),
+              'gpsmi_trk_create')
+        self.h = h
+        for p in prns:
+            rep = np.ascontiguousarray(
+                codes.code_replica(p, self.cfg.code_samples).astype(np.float32))
+            spec = _spectrum_c64(p, self.cfg.code_samples)
+            check(self.lib.gpsmi_trk_set_replica(self.h, p, ptr(rep), ptr(spec)),
+                  'gpsmi_trk_set_replica')
+
+    def open(self, ch, prn, freq, delay):
+        check(self.lib.gpsmi_trk_open(self.h, ch, prn, float(freq), int(delay)),
+              'gpsmi_trk_open')
+
+    def close_channel(self, ch):
+        check(self.lib.gpsmi_trk_close(self.h, ch), 'gpsmi_trk_close')
+
+    def get_state(self, ch):
+        st = np.zeros(1, dtype=STATE_DTYPE)
+        check(self.lib.gpsmi_trk_get_state(self.h, ch, ptr(st)),
+              'gpsmi_trk_get_state')
+        return st[0]
+
+    def set_state(self, ch, st):
+        a = np.zeros(1, dtype=STATE_DTYPE)
+        a[0] = st
+        check(self.lib.gpsmi_trk_set_state(self.h, ch, ptr(a)),
+              'gpsmi_trk_set_state')
+
+    def erase_prev(self, ch):
+        check(self.lib.gpsmi_trk_erase_prev(self.h, ch), 'gpsmi_trk_erase_prev')
+
+    def process(self, iq, want_out=True):
+        """One closed-loop block for every open channel.  iq: complex64[NGPS]
+        on the host, or a c_void_p to a device-resident block."""
+        out = np.zeros(self.max_ch, dtype=OUT_DTYPE) if want_out else None
+        if isinstance(iq, C.c_void_p):
+            check(self.lib.gpsmi_trk_process_dev(self.h, iq, self.cfg.ngps,
+                                                 ptr(out)),
+                  'gpsmi_trk_process_dev')
+        else:
+            iq = np.ascontiguousarray(iq, dtype=np.complex64)
+            if out is None:
+                out = np.zeros(self.max_ch, dtype=OUT_DTYPE)
+            check(self.lib.gpsmi_trk_process(self.h, ptr(iq), iq.size, ptr(out)),
+                  'gpsmi_trk_process')
+        return out
+
+    def replay(self, d_iq, nb, table, delay_used=None):
+        """nb device-resident blocks, states at block start [nb, max_ch]."""
+        table = np.ascontiguousarray(table, dtype=STATE_DTYPE)
+        if table.shape != (nb, self.max_ch):
+            raise ValueError('table must be [nb, max_ch]')
+        if delay_used is not None:
+            delay_used = np.ascontiguousarray(delay_used, dtype=np.int32)
+            if delay_used.shape != (nb, self.max_ch):
+                raise ValueError('delay_used must be [nb, max_ch]')
+        out = np.zeros((nb, self.max_ch), dtype=OUT_DTYPE)
+        check(self.lib.gpsmi_trk_replay(self.h, d_iq, nb, ptr(table),
+                                        ptr(delay_used), ptr(out)),
+              'gpsmi_trk_replay')
+        return out
+
+    def replay_states(self, nb):
+        st = np.zeros((nb, self.max_ch), dtype=STATE_DTYPE)
+        check(self.lib.gpsmi_trk_replay_states(self.h, ptr(st), st.size),
+              'gpsmi_trk_replay_states')
+        return st
+
+    def last_ms(self):
+        a, b = C.c_float(0), C.c_float(0)
+        check(self.lib.gpsmi_trk_last_ms(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def close(self):
+        if self.h:
+            self.lib.gpsmi_trk_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def dumps_of(rec):
+    """complex64 prompt dumps of one gpsmi_trk_out record."""
+    n = int(rec['n_dumps'])
+    d = rec['dumps']
+    return (d[0:2 * n:2] + 1j * d[1:2 * n:2]).astype(np.complex64)

@@ -1,0 +1,228 @@
+/*
+ * gpsmi.h -- C ABI of libgpsmi.so: GPS L1 C/A acquisition and tracking on MI355X.
+ *
+ * Plain C, plain pointers and sizes.  The reference receiver
+ * (annappo/GPS-SDR-Receiver) has no FFI of its own: its hot path is three
+ * Python call sites.  Each entry point below names the reference interface it
+ * stands in for (file:line into the reference's src/); INTEGRATION.md shows the
+ * ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - every function returns 0 (GPSMI_OK) or a negative GPSMI_E_* code and never
+ *    throws or aborts; gpsmi_last_error() returns the text of the last failure
+ *    on the calling thread (it carries the hipError_t string when there is one);
+ *  - "no correlation" is in-band, as in the reference: delay = -1,
+ *    code_phase = -1.0 (gpslib.py:1296-1304), not an error;
+ *  - the caller owns all host buffers; no pointer is retained after return;
+ *    device memory is owned by the handle (or by gpsmi_dev_alloc/free);
+ *  - one handle is used by one host thread at a time; each handle has its own
+ *    HIP stream; distinct handles are independent;
+ *  - complex samples are interleaved float pairs (numpy complex64), "iq" counts
+ *    are in complex samples.
+ */
+#ifndef GPSMI_H
+#define GPSMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPSMI_OK            0
+#define GPSMI_E_ARG        -1   /* bad argument (null, range, size)              */
+#define GPSMI_E_HIP        -2   /* a HIP runtime call failed; see last_error     */
+#define GPSMI_E_STATE      -3   /* channel not open / handle not configured      */
+#define GPSMI_E_NOMEM      -4
+#define GPSMI_E_UNSUPPORTED -5  /* e.g. code_samples that is not a power of two  */
+#define GPSMI_E_COMM       -6   /* RCCL failure                                  */
+
+#define GPSMI_MAX_PRN      37
+#define GPSMI_MAX_DUMPS    33   /* N_CYC + 1 prompt dumps (gpslib.py:1418-1439)  */
+#define GPSMI_MAX_DF       128  /* entries of the PLL drift list (1024 / N_CYC)  */
+
+/* Module constants of gpsglob.py:35-131 that the path depends on. */
+typedef struct gpsmi_cfg {
+    int32_t code_samples;    /* CODE_SAMPLES  gpsglob.py:119  (power of two)     */
+    int32_t n_cyc;           /* N_CYC         gpsglob.py:122                     */
+    int32_t corr_avg;        /* CORR_AVG      gpsglob.py:63                      */
+    int32_t sweep_corr_avg;  /* SWEEP_CORR_AVG gpsglob.py:67                     */
+    float   corr_min;        /* CORR_MIN      gpsglob.py:65                      */
+    float   min_freq;        /* MIN_FREQ      gpsglob.py:72                      */
+    float   max_freq;        /* MAX_FREQ      gpsglob.py:73                      */
+    int32_t device;          /* HIP device ordinal                               */
+} gpsmi_cfg;
+
+const char* gpsmi_last_error(void);
+const char* gpsmi_version(void);
+/* sizeof() of the ABI structs as compiled: 0 cfg, 1 peak, 2 trk_state, 3 trk_out,
+ * 4 offsetof(trk_out, code_phase); -1 otherwise.  Lets a binding verify its
+ * own struct declarations before the first real call.                        */
+int gpsmi_abi_sizeof(int which);
+int gpsmi_device_count(int* n);
+int gpsmi_device_name(int device, char* buf, size_t len);
+
+/* ---- device buffers (IQ kept resident in HBM between calls) ------------- */
+int gpsmi_dev_alloc(int device, size_t bytes, void** dptr);
+int gpsmi_dev_free(int device, void* dptr);
+int gpsmi_dev_upload(int device, void* dptr, const void* host, size_t bytes);
+int gpsmi_dev_download(int device, void* host, const void* dptr, size_t bytes);
+int gpsmi_dev_sync(int device);
+/* streamData's decode on the device (gpsrecv.py:168-173): raw uint16 (Q<<8|I)
+ * -> complex64 (I + jQ)/127.5 - (1+1j); both pointers are device pointers.  */
+int gpsmi_dev_unpack_u8iq(int device, void* d_iq_c64, const void* d_raw_u16,
+                          size_t n_samples);
+
+/* ========================================================================
+ * Acquisition -- replaces the array arithmetic of gpsrecv.sweepAllSats
+ * (gpsrecv.py:241-274): demodDoppler (:232-235), the n_avg folded FFTs
+ * (:250-254), abs(ifft(X*conj(FFT_CACODE[sv]))) (:258) and the statistics of
+ * findCodePhase (:217-223).  First-hit bookkeeping (:256-272), sorting (:274)
+ * and getNewSats (:423-440) stay on the host over the returned table.
+ * ======================================================================== */
+typedef struct gpsmi_acq gpsmi_acq;
+
+/* One cell of the search surface: first-index argmax, its value, mean and
+ * population standard deviation of |corr| over the code_samples lags.        */
+typedef struct gpsmi_peak {
+    int32_t argmax;
+    float   peak;
+    float   mean;
+    float   std;
+} gpsmi_peak;
+
+int gpsmi_acq_create(const gpsmi_cfg* cfg, gpsmi_acq** out);
+int gpsmi_acq_destroy(gpsmi_acq* h);
+/* FFT_CACODE[prn] (gpsrecv.py:574-577): spectrum of the sampled replica,
+ * complex64 [code_samples]; the host computes it once (gpsmi.codes).         */
+int gpsmi_acq_set_replica(gpsmi_acq* h, int prn, const float* spectrum_c64);
+/* Search nbins Doppler bins x nsv satellites on the first n_avg code periods of
+ * iq.  freqs_hz[b] are the bin frequencies exactly as the reference steps them
+ * (python floats); out is [nbins][nsv].  iq: host complex64, n >= n_avg*cs.   */
+int gpsmi_acq_search(gpsmi_acq* h, const float* iq, size_t n,
+                     const int32_t* prn, int nsv,
+                     const double* freqs_hz, int nbins, int n_avg,
+                     gpsmi_peak* out);
+/* Same with iq already on the device; out_dev (optional) receives the table in
+ * device memory as well (for the RCCL gather), out (optional) on the host.    */
+int gpsmi_acq_search_dev(gpsmi_acq* h, const void* d_iq, size_t n,
+                         const int32_t* prn, int nsv,
+                         const double* freqs_hz, int nbins, int n_avg,
+                         gpsmi_peak* out, void* out_dev);
+/* Timing of the last search on the handle's stream (HIP events), ms.          */
+int gpsmi_acq_last_ms(gpsmi_acq* h, float* ms);
+
+/* ========================================================================
+ * Tracking -- replaces the numeric part of gpslib.SatStream.process
+ * (gpslib.py:1141-1210) for all channels of one device in one call:
+ * demodDoppler (:1343-1346), cacodeCorr (:1315-1327), findCodePhase and
+ * fitCodePhase (:1293-1304, :1268-1290), decodeData's integrate-and-dump
+ * (:1400-1420, :1439-1440), the amplitude statistics (:1186-1188) and
+ * phaseLockedLoop (:1215-1262) with the state update (:1205-1208).
+ * The per-SV worker processes of gpsrecv.runProc (gpsrecv.py:300-337)
+ * collapse into channels of one handle.
+ * ======================================================================== */
+typedef struct gpsmi_trk gpsmi_trk;
+
+/* Loop-carried state of one channel (SatStream.__init__, gpslib.py:1050-1091).
+ * freq and phase are float32 because they are float32 in the reference under
+ * numpy >= 2.                                                  */
+typedef struct gpsmi_trk_state {
+    int32_t prn;             /* SAT_NO; 0 = channel closed                     */
+    int32_t delay;           /* DELAY                                          */
+    float   freq;            /* FREQ, Hz                                       */
+    float   phase;           /* PHASE, rad                                     */
+    int32_t phase_locked;    /* PHASE_LOCKED                                   */
+    int32_t nps;             /* len(PREV_SAMPLES)                              */
+    float   prev_sum_re;     /* sum(PREV_SAMPLES): the carry is only ever used */
+    float   prev_sum_im;     /*   inside the first window's mean (:1405-1419)  */
+    int32_t df_len;          /* len(DF)                                        */
+    float   omega0;          /* 2*pi*FREQ while FREQ is still a Python float    */
+                             /*   (after initInst or a clamp): float32 of the   */
+                             /*   float64 product.  0 = FREQ is float32 and the */
+                             /*   factor is float32(2*pi)*FREQ (NEP 50)         */
+    float   df[GPSMI_MAX_DF];/* DF, oldest first                               */
+} gpsmi_trk_state;
+
+/* Everything SatStream.process and its callers read back for one block.       */
+typedef struct gpsmi_trk_out {
+    int32_t prn;
+    int32_t n_dumps;                     /* len(gpsData), N_CYC or N_CYC+1      */
+    float   dumps[2 * GPSMI_MAX_DUMPS];  /* gpsData, complex64 (:1439)          */
+    int32_t first_len;                   /* samples in the first window         */
+    int32_t mx;                          /* argmax of corr                      */
+    float   epl[3];                      /* corr[mx-1], corr[mx], corr[mx+1]    */
+    float   corr_mean, corr_std;
+    float   norm_max_corr;               /* MAX_CORR (:1188)                    */
+    int32_t delay;                       /* findCodePhase delay, -1 below CORR_MIN */
+    double  code_phase;                  /* fitCodePhase, -1.0 below CORR_MIN   */
+    int32_t delay_used;                  /* DELAY after the block (:1181-1182)  */
+    float   std_dev, amplitude;          /* STD_DEV, AMPLITUDE (:1186-1187)     */
+    float   df, phase_shift;             /* PLL outputs (:1205-1206)            */
+    float   freq, phase;                 /* FREQ, PHASE after the block         */
+    int32_t phase_locked;                /* PHASE_LOCKED after the block        */
+    int32_t nps;                         /* len(PREV_SAMPLES) after the block   */
+} gpsmi_trk_out;
+
+int gpsmi_trk_create(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk** out);
+int gpsmi_trk_destroy(gpsmi_trk* h);
+/* GPSCacode(prn) as float32 [code_samples] and its spectrum, complex64.       */
+int gpsmi_trk_set_replica(gpsmi_trk* h, int prn, const float* replica_f32,
+                          const float* spectrum_c64);
+/* ('initInst',(satNo,freq,delay)) of gpsrecv.py:312-321.                      */
+int gpsmi_trk_open(gpsmi_trk* h, int ch, int prn, float freq_hz, int delay);
+/* ('delInst',None) of gpsrecv.py:323-328.                                     */
+int gpsmi_trk_close(gpsmi_trk* h, int ch);
+int gpsmi_trk_get_state(gpsmi_trk* h, int ch, gpsmi_trk_state* st);
+int gpsmi_trk_set_state(gpsmi_trk* h, int ch, const gpsmi_trk_state* st);
+/* erasePrevData / setPhaseUnlocked (gpslib.py:1095-1107) for one channel.     */
+int gpsmi_trk_erase_prev(gpsmi_trk* h, int ch);
+
+/* ('runInst',(data,smpTime)) for every open channel (gpsrecv.py:330-334,
+ * :404-417): one closed-loop block.  iq: host complex64 [NGPS].  out[ch] is
+ * written for open channels, out[ch].prn = 0 for closed ones.                 */
+int gpsmi_trk_process(gpsmi_trk* h, const float* iq, size_t n,
+                      gpsmi_trk_out* out);
+/* Same on a block that is already in device memory.  out may be NULL when the
+ * caller only wants the state to advance (read it later with get_state).      */
+int gpsmi_trk_process_dev(gpsmi_trk* h, const void* d_iq, size_t n,
+                          gpsmi_trk_out* out);
+
+/* Replay (open loop): nb blocks resident in device memory, the state at the
+ * START of every block supplied as a table [nb][nch] (one row per block, one
+ * column per open channel in channel order), all blocks processed in one batch.
+ * delay_used[nb][nch] is the DELAY each block decodes with (the closed loop
+ * derives it from the same block's correlation; in replay it comes from the
+ * recorded trajectory and the kernel's own result is returned for comparison).
+ * out is [nb][nch].  Running the closed loop and replaying its recorded
+ * trajectory give the same outputs.                                           */
+int gpsmi_trk_replay(gpsmi_trk* h, const void* d_iq, int nb,
+                     const gpsmi_trk_state* table, const int32_t* delay_used,
+                     gpsmi_trk_out* out);
+/* State at the END of every job of the last replay, [nb][nch]: equals the next
+ * row of the table when the table is a closed-loop trajectory.               */
+int gpsmi_trk_replay_states(gpsmi_trk* h, gpsmi_trk_state* states, size_t n);
+/* Device time of the last process/replay call (HIP events on the handle's
+ * stream), total and for the correlator kernel alone, ms.                     */
+int gpsmi_trk_last_ms(gpsmi_trk* h, float* total_ms, float* correlator_ms);
+
+/* ========================================================================
+ * Multi-GPU: one process per GPU; SVs / blocks are sharded by the host and
+ * the only exchange is a gather of fixed-size peak records over RCCL.
+ * ======================================================================== */
+typedef struct gpsmi_comm gpsmi_comm;
+#define GPSMI_COMM_ID_BYTES 128
+int gpsmi_comm_unique_id(void* id_bytes);             /* rank 0, then broadcast */
+int gpsmi_comm_create(const void* id_bytes, int nranks, int rank, int device,
+                      gpsmi_comm** out);
+int gpsmi_comm_destroy(gpsmi_comm* c);
+/* all-gather of `count` peak records per rank; d_send [count], d_recv
+ * [nranks*count], both device pointers; host_recv (optional) gets a copy.     */
+int gpsmi_comm_allgather_peaks(gpsmi_comm* c, const void* d_send, void* d_recv,
+                               int count, gpsmi_peak* host_recv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPSMI_H */

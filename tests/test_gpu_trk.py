@@ -1,0 +1,197 @@
+"""GPU parity: tracking through the C ABI vs the reference fixtures
+(gpslib.SatStream.process over 48 consecutive blocks x 12 channels).
+
+Bars: argmax / DELAY / dump count / carry length bit-exact;
+prompt dumps rtol 1e-3 + atol 1e-5; the three correlator taps around the peak
+rtol 1e-3; codePhase atol 2e-3 samples; FREQ atol 0.05 Hz; lock flag equal
+after the same number of blocks."""
+import numpy as np
+import pytest
+
+from conftest import scene_blocks
+
+pytestmark = pytest.mark.gpu
+
+
+def _open_all(eng, g):
+    for c, (sv, f0, d0) in enumerate(g['trk_init']):
+        eng.open(c, int(sv), float(f0), int(d0))
+    return len(g['trk_init'])
+
+
+@pytest.fixture(scope='module')
+def closed_loop(golden_default):
+    """Run the closed loop once over the fixture blocks; keep every output and
+    the state at the start of every block."""
+    from gpsmi.engine import TrkEngine, STATE_DTYPE
+    g = golden_default
+    nch, nb = g['trk_delay'].shape
+    eng = TrkEngine(max_ch=nch)
+    _open_all(eng, g)
+    blocks = scene_blocks('default', 5, nb)
+    outs, states = [], []
+    for i in range(nb):
+        st = np.zeros(nch, dtype=STATE_DTYPE)
+        for c in range(nch):
+            st[c] = eng.get_state(c)
+        states.append(st)
+        outs.append(eng.process(blocks[i]))
+    yield eng, np.array(outs), np.array(states), blocks
+    eng.close()
+
+
+def test_closed_loop_matches_reference(closed_loop, golden_default):
+    from gpsmi.engine import dumps_of
+    g = golden_default
+    _, outs, _, _ = closed_loop
+    nb, nch = outs.shape
+    for c in range(nch):
+        for i in range(nb):
+            o = outs[i, c]
+            where = f'channel {c} block {i}'
+            assert o['prn'] == int(g['trk_init'][c, 0])
+            assert o['mx'] == int(g['trk_mx'][c, i]), where
+            assert o['delay_used'] == int(g['trk_delay'][c, i]), where
+            assert o['n_dumps'] == int(g['trk_n_dumps'][c, i]), where
+            assert o['nps'] == int(g['trk_nps'][c, i]), where
+            nd = int(o['n_dumps'])
+            np.testing.assert_allclose(dumps_of(o), g['trk_dumps'][c, i, :nd],
+                                       rtol=1e-3, atol=1e-5, err_msg=where)
+            np.testing.assert_allclose(o['epl'], g['trk_epl'][c, i], rtol=1e-3,
+                                       err_msg=where)
+            np.testing.assert_allclose(o['corr_mean'], g['trk_corr_mean'][c, i],
+                                       rtol=1e-4)
+            np.testing.assert_allclose(o['corr_std'], g['trk_corr_std'][c, i],
+                                       rtol=1e-4)
+            np.testing.assert_allclose(o['norm_max_corr'], g['trk_norm'][c, i],
+                                       rtol=1e-3)
+            cp = g['trk_code_phase'][c, i]
+            if cp < 0:
+                assert o['code_phase'] == -1.0 and o['delay'] == -1, where
+            else:
+                assert abs(o['code_phase'] - cp) < 2e-3, where
+            assert abs(o['freq'] - g['trk_freq'][c, i]) < 0.05, where
+            assert bool(o['phase_locked']) == bool(g['trk_locked'][c, i]), where
+            np.testing.assert_allclose(o['std_dev'], g['trk_std_dev'][c, i],
+                                       rtol=2e-3, err_msg=where)
+            np.testing.assert_allclose(o['amplitude'], g['trk_amplitude'][c, i],
+                                       rtol=2e-3, err_msg=where)
+            # phase is only defined modulo 2 pi in the reference too
+            dph = (o['phase'] - g['trk_phase'][c, i] + np.pi) % (2 * np.pi) - np.pi
+            assert abs(dph) < 2e-3, where
+
+
+def test_replay_reproduces_closed_loop(closed_loop):
+    """Replay of the recorded trajectory gives the closed loop's outputs, and
+    its end-of-block states equal the next row of the table."""
+    from gpsmi.engine import DeviceBuffer
+    eng, outs, states, blocks = closed_loop
+    nb, nch = outs.shape
+    buf = DeviceBuffer(nb * blocks[0].nbytes)
+    for i, b in enumerate(blocks):
+        buf.upload(b, i * b.nbytes)
+    rep = eng.replay(buf.ptr, nb, states, outs['delay_used'])
+    nxt = eng.replay_states(nb)
+    buf.free()
+    assert rep.tobytes() == outs.tobytes()
+    for k in ('prn', 'delay', 'freq', 'phase', 'phase_locked', 'nps',
+              'prev_sum_re', 'prev_sum_im', 'df_len', 'omega0'):
+        assert np.array_equal(nxt[:-1][k], states[1:][k]), k
+    for i in range(nb - 1):
+        for c in range(nch):
+            n = int(states[i + 1, c]['df_len'])
+            assert np.array_equal(nxt[i, c]['df'][:n], states[i + 1, c]['df'][:n])
+
+
+def test_replay_without_forced_delay(closed_loop):
+    """With no recorded DELAY given, replay derives it from each block's own
+    correlation, exactly as the closed loop does."""
+    from gpsmi.engine import DeviceBuffer
+    eng, outs, states, blocks = closed_loop
+    nb = 6
+    buf = DeviceBuffer(nb * blocks[0].nbytes)
+    for i in range(nb):
+        buf.upload(blocks[i], i * blocks[i].nbytes)
+    rep = eng.replay(buf.ptr, nb, states[:nb], None)
+    buf.free()
+    assert rep.tobytes() == outs[:nb].tobytes()
+
+
+def test_block_from_device_memory(golden_default):
+    """process() on a device-resident block equals process() on a host block."""
+    from gpsmi.engine import TrkEngine, DeviceBuffer
+    g = golden_default
+    blocks = scene_blocks('default', 5, 2)
+    res = []
+    for dev in (False, True):
+        eng = TrkEngine(max_ch=4)
+        for c in range(4):
+            sv, f0, d0 = g['trk_init'][c]
+            eng.open(c, int(sv), float(f0), int(d0))
+        outs = []
+        for b in blocks:
+            if dev:
+                buf = DeviceBuffer(b.nbytes)
+                buf.upload(b)
+                outs.append(eng.process(buf.ptr))
+                buf.free()
+            else:
+                outs.append(eng.process(b))
+        res.append(np.array(outs).tobytes())
+        eng.close()
+    assert res[0] == res[1]
+
+
+def test_first_window_rules():
+    """decodeData's window edge cases (gpslib.py:1408-1419, :1440) on a clean
+    signal: empty carry with delay 0, a partial first window, and the
+    2047 -> 0 wrap that yields N_CYC + 1 dumps."""
+    from gpsmi import codes
+    from gpsmi.engine import TrkEngine, dumps_of
+    rep = codes.code_replica(9)
+    cs, ncyc = 2048, 32
+
+    def block(delay):
+        return (0.4 * np.tile(np.roll(rep, delay), ncyc)).astype(np.complex64)
+
+    eng = TrkEngine(max_ch=1)
+    eng.open(0, 9, 0.0, 0)
+    o = eng.process(block(0))[0]                  # NPS = 0, delay 0
+    assert (o['n_dumps'], o['first_len'], o['nps'], o['delay_used']) == (32, cs, 0, 0)
+    eng.close()
+
+    eng = TrkEngine(max_ch=1)
+    eng.open(0, 9, 0.0, 2047)
+    o = eng.process(block(2047))[0]               # partial first window
+    assert (o['n_dumps'], o['first_len'], o['nps']) == (32, 2047, 1)
+    d = dumps_of(o)
+    assert np.allclose(d.real[1:], d.real[1], rtol=1e-5)
+    o = eng.process(block(0))[0]                  # carry of 1 sample, delay 0
+    assert o['delay_used'] == 0
+    assert (o['n_dumps'], o['first_len'], o['nps']) == (33, 1, 0)
+    o = eng.process(block(0))[0]
+    assert (o['n_dumps'], o['first_len'], o['nps']) == (32, cs, 0)
+    eng.close()
+
+
+def test_channel_management_and_errors():
+    from gpsmi.engine import TrkEngine, EngineError
+    eng = TrkEngine(max_ch=3, prns=[3, 4])
+    with pytest.raises(EngineError):
+        eng.open(3, 3, 0.0, 0)                    # channel out of range
+    with pytest.raises(EngineError):
+        eng.open(0, 5, 0.0, 0)                    # no replica for PRN 5
+    with pytest.raises(EngineError):
+        eng.open(0, 3, 0.0, 2048)                 # delay out of range
+    with pytest.raises(EngineError):
+        eng.close_channel(1)                      # not open
+    with pytest.raises(EngineError):
+        eng.process(np.zeros(100, np.complex64))  # ragged block
+    eng.open(1, 4, 250.0, 17)
+    st = eng.get_state(1)
+    assert (st['prn'], st['delay'], st['freq'], st['df_len']) == (4, 17, 250.0, 1)
+    out = eng.process(np.zeros(65536, np.complex64))
+    assert out[0]['prn'] == 0 and out[2]['prn'] == 0 and out[1]['prn'] == 4
+    eng.close_channel(1)
+    assert eng.get_state(1)['prn'] == 0
+    eng.close()
