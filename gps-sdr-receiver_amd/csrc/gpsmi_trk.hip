@@ -191,6 +191,7 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(
             cp = fit_code_phase((double)red[16], (double)bv, (double)red[17], bi);
         }
         o.delay = delay;
+        o.reserved0 = 0;
         o.code_phase = cp;
         int used = delay >= 0 ? delay : st.delay;
         if (delay_forced && delay_forced[job] >= 0) used = delay_forced[job];
@@ -383,6 +384,7 @@ __global__ __launch_bounds__(64) void trk_epilogue_kernel(
     o.phase = phase;
     o.phase_locked = locked;
     o.nps = nps_new;
+    o.reserved1 = 0;
 }
 
 }  // namespace gpsmi
@@ -438,6 +440,8 @@ static int trk_launch(gpsmi_trk* h, const float2* d_iq, const gpsmi_trk_state* s
                       gpsmi_trk_state* st_out, const int* forced, int njobs, int nch) {
     TrkParams P = h->P;
     P.nch = nch;
+    // records of closed channels stay all-zero (prn = 0)
+    GPSMI_HIP(hipMemsetAsync(h->d_out, 0, (size_t)njobs * sizeof(gpsmi_trk_out), h->stream));
     GPSMI_HIP(hipEventRecord(h->ev[0], h->stream));
     hipLaunchKernelGGL(trk_corr_kernel, dim3(njobs), dim3(256), 0, h->stream, d_iq, st_in, forced,
                        h->d_t32, h->d_rep, h->d_tw, P, h->d_out, h->d_mid);

@@ -44,11 +44,12 @@ OUT_DTYPE = np.dtype([
     ('dumps', np.float32, (2 * MAX_DUMPS,)),
     ('first_len', np.int32), ('mx', np.int32), ('epl', np.float32, (3,)),
     ('corr_mean', np.float32), ('corr_std', np.float32),
-    ('norm_max_corr', np.float32), ('delay', np.int32),
+    ('norm_max_corr', np.float32), ('delay', np.int32), ('reserved0', np.int32),
     ('code_phase', np.float64), ('delay_used', np.int32),
     ('std_dev', np.float32), ('amplitude', np.float32), ('df', np.float32),
     ('phase_shift', np.float32), ('freq', np.float32), ('phase', np.float32),
-    ('phase_locked', np.int32), ('nps', np.int32)], align=True)
+    ('phase_locked', np.int32), ('nps', np.int32), ('reserved1', np.int32)],
+    align=True)
 
 EXPORTS = [
     'gpsmi_last_error', 'gpsmi_version', 'gpsmi_abi_sizeof',

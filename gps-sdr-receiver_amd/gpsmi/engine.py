@@ -117,7 +117,7 @@ def _spectrum_c64(prn, cs):
 class AcqEngine:
     """Search surface of gpsrecv.sweepAllSats (reference gpsrecv.py:241-274)."""
 
-    def __init__(self, cfg=None, prns=range(1, 33)):
+    def __init__(self, cfg=None, prns=range(1, 38)):
         self.cfg = cfg or Config()
         self.lib = _lib.load()
         h = C.c_void_p()
@@ -169,7 +169,7 @@ class TrkEngine:
     """All tracking channels of one GPU (numeric part of SatStream.process,
     reference gpslib.py:1141-1210)."""
 
-    def __init__(self, cfg=None, max_ch=12, prns=range(1, 33)):
+    def __init__(self, cfg=None, max_ch=12, prns=range(1, 38)):
         self.cfg = cfg or Config()
         self.max_ch = max_ch
         self.lib = _lib.load()

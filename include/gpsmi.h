@@ -156,6 +156,7 @@ typedef struct gpsmi_trk_out {
     float   corr_mean, corr_std;
     float   norm_max_corr;               /* MAX_CORR (:1188)                    */
     int32_t delay;                       /* findCodePhase delay, -1 below CORR_MIN */
+    int32_t reserved0;                   /* 0 (keeps code_phase 8-aligned)      */
     double  code_phase;                  /* fitCodePhase, -1.0 below CORR_MIN   */
     int32_t delay_used;                  /* DELAY after the block (:1181-1182)  */
     float   std_dev, amplitude;          /* STD_DEV, AMPLITUDE (:1186-1187)     */
@@ -163,6 +164,7 @@ typedef struct gpsmi_trk_out {
     float   freq, phase;                 /* FREQ, PHASE after the block         */
     int32_t phase_locked;                /* PHASE_LOCKED after the block        */
     int32_t nps;                         /* len(PREV_SAMPLES) after the block   */
+    int32_t reserved1;                   /* 0 (no implicit tail padding)        */
 } gpsmi_trk_out;
 
 int gpsmi_trk_create(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk** out);

@@ -9,4 +9,4 @@ sys.path.insert(0, 'gps-sdr-receiver_amd')
 from gpsmi import engine
 print('devices:', engine.device_count(), engine.device_name(0))
 PY
-python -m pytest tests -m gpu -x -q 2>&1 | tee gpurun_out/pytest_gpu.log
+python -m pytest tests -m gpu -q 2>&1 | tee gpurun_out/pytest_gpu.log
