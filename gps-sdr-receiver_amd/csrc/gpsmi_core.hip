@@ -109,6 +109,18 @@ int gpsmi_dev_download(int device, void* host, const void* dptr, size_t bytes) {
     return GPSMI_OK;
 }
 
+int gpsmi_host_alloc(size_t bytes, void** hptr) {
+    GPSMI_REQUIRE(hptr && bytes > 0, "null pointer or zero size");
+    GPSMI_HIP(hipHostMalloc(hptr, bytes, hipHostMallocDefault));
+    return GPSMI_OK;
+}
+
+int gpsmi_host_free(void* hptr) {
+    if (!hptr) return GPSMI_OK;
+    GPSMI_HIP(hipHostFree(hptr));
+    return GPSMI_OK;
+}
+
 int gpsmi_dev_sync(int device) {
     GPSMI_HIP(hipSetDevice(device));
     GPSMI_HIP(hipDeviceSynchronize());

@@ -415,6 +415,8 @@ struct gpsmi_trk {
     float4* d_partial = nullptr;
     gpsmi_trk_out* d_out = nullptr;
     float last_total_ms = 0.f, last_corr_ms = 0.f;
+    int replay_nb = 0;
+    bool replay_forced = false;
     TrkParams P;
 };
 
@@ -639,11 +641,10 @@ int gpsmi_trk_process(gpsmi_trk* h, const float* iq, size_t n, gpsmi_trk_out* ou
     return gpsmi_trk_process_dev(h, h->d_block, n, out);
 }
 
-int gpsmi_trk_replay(gpsmi_trk* h, const void* d_iq, int nb, const gpsmi_trk_state* table,
-                     const int32_t* delay_used, gpsmi_trk_out* out) {
-    GPSMI_REQUIRE(h && d_iq && table && out, "null argument");
-    GPSMI_REQUIRE(nb >= 0, "negative block count");
-    if (nb == 0) return GPSMI_OK;
+int gpsmi_trk_replay_load(gpsmi_trk* h, int nb, const gpsmi_trk_state* table,
+                          const int32_t* delay_used) {
+    GPSMI_REQUIRE(h && table, "null argument");
+    GPSMI_REQUIRE(nb >= 1, "block count must be >= 1");
     GPSMI_HIP(hipSetDevice(h->cfg.device));
     const int nch = h->max_ch;
     const size_t njobs = (size_t)nb * nch;
@@ -664,20 +665,54 @@ int gpsmi_trk_replay(gpsmi_trk* h, const void* d_iq, int nb, const gpsmi_trk_sta
     if (delay_used)
         GPSMI_HIP(hipMemcpyAsync(h->d_forced, delay_used, njobs * sizeof(int),
                                  hipMemcpyHostToDevice, h->stream));
-    rc = trk_launch(h, (const float2*)d_iq, h->d_tab_in, h->d_tab_out,
-                    delay_used ? h->d_forced : nullptr, (int)njobs, nch);
+    GPSMI_HIP(hipStreamSynchronize(h->stream));
+    h->replay_nb = nb;
+    h->replay_forced = delay_used != nullptr;
+    return GPSMI_OK;
+}
+
+int gpsmi_trk_replay_run(gpsmi_trk* h, const void* d_iq, int nb) {
+    GPSMI_REQUIRE(h && d_iq, "null argument");
+    if (nb != h->replay_nb || nb < 1)
+        return fail(GPSMI_E_STATE, "replay_run(nb=%d) without a matching replay_load (nb=%d)", nb,
+                    h->replay_nb);
+    GPSMI_HIP(hipSetDevice(h->cfg.device));
+    const int nch = h->max_ch;
+    int rc = trk_launch(h, (const float2*)d_iq, h->d_tab_in, h->d_tab_out,
+                        h->replay_forced ? h->d_forced : nullptr, nb * nch, nch);
     if (rc) return rc;
-    GPSMI_HIP(hipMemcpyAsync(out, h->d_out, njobs * sizeof(gpsmi_trk_out), hipMemcpyDeviceToHost,
-                             h->stream));
     GPSMI_HIP(hipStreamSynchronize(h->stream));
     GPSMI_HIP(hipEventElapsedTime(&h->last_total_ms, h->ev[0], h->ev[3]));
     GPSMI_HIP(hipEventElapsedTime(&h->last_corr_ms, h->ev[1], h->ev[2]));
     return GPSMI_OK;
 }
 
+int gpsmi_trk_replay_fetch(gpsmi_trk* h, gpsmi_trk_out* out, size_t n) {
+    GPSMI_REQUIRE(h && out, "null argument");
+    GPSMI_REQUIRE(n <= (size_t)h->replay_nb * h->max_ch, "more records than the last replay ran");
+    GPSMI_HIP(hipSetDevice(h->cfg.device));
+    GPSMI_HIP(hipMemcpyAsync(out, h->d_out, n * sizeof(gpsmi_trk_out), hipMemcpyDeviceToHost,
+                             h->stream));
+    GPSMI_HIP(hipStreamSynchronize(h->stream));
+    return GPSMI_OK;
+}
+
+int gpsmi_trk_replay(gpsmi_trk* h, const void* d_iq, int nb, const gpsmi_trk_state* table,
+                     const int32_t* delay_used, gpsmi_trk_out* out) {
+    GPSMI_REQUIRE(h && d_iq && table && out, "null argument");
+    GPSMI_REQUIRE(nb >= 0, "negative block count");
+    if (nb == 0) return GPSMI_OK;
+    int rc = gpsmi_trk_replay_load(h, nb, table, delay_used);
+    if (rc) return rc;
+    rc = gpsmi_trk_replay_run(h, d_iq, nb);
+    if (rc) return rc;
+    return gpsmi_trk_replay_fetch(h, out, (size_t)nb * h->max_ch);
+}
+
 int gpsmi_trk_replay_states(gpsmi_trk* h, gpsmi_trk_state* states, size_t n) {
     GPSMI_REQUIRE(h && states, "null argument");
-    GPSMI_REQUIRE(n <= h->njobs_cap, "more states requested than the last replay produced");
+    GPSMI_REQUIRE(n <= (size_t)h->replay_nb * h->max_ch,
+                  "more states requested than the last replay produced");
     GPSMI_HIP(hipSetDevice(h->cfg.device));
     GPSMI_HIP(hipMemcpy(states, h->d_tab_out, n * sizeof(gpsmi_trk_state), hipMemcpyDeviceToHost));
     return GPSMI_OK;

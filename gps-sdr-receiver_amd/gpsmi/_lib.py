@@ -56,13 +56,15 @@ EXPORTS = [
     'gpsmi_device_count',
     'gpsmi_device_name', 'gpsmi_dev_alloc', 'gpsmi_dev_free',
     'gpsmi_dev_upload', 'gpsmi_dev_download', 'gpsmi_dev_sync',
+    'gpsmi_host_alloc', 'gpsmi_host_free',
     'gpsmi_dev_unpack_u8iq',
     'gpsmi_acq_create', 'gpsmi_acq_destroy', 'gpsmi_acq_set_replica',
     'gpsmi_acq_search', 'gpsmi_acq_search_dev', 'gpsmi_acq_last_ms',
     'gpsmi_trk_create', 'gpsmi_trk_destroy', 'gpsmi_trk_set_replica',
     'gpsmi_trk_open', 'gpsmi_trk_close', 'gpsmi_trk_get_state',
     'gpsmi_trk_set_state', 'gpsmi_trk_erase_prev', 'gpsmi_trk_process',
-    'gpsmi_trk_process_dev', 'gpsmi_trk_replay', 'gpsmi_trk_replay_states',
+    'gpsmi_trk_process_dev', 'gpsmi_trk_replay', 'gpsmi_trk_replay_load',
+    'gpsmi_trk_replay_run', 'gpsmi_trk_replay_fetch', 'gpsmi_trk_replay_states',
     'gpsmi_trk_last_ms',
     'gpsmi_comm_unique_id', 'gpsmi_comm_create', 'gpsmi_comm_destroy',
     'gpsmi_comm_allgather_peaks',
@@ -118,6 +120,11 @@ def load():
         'gpsmi_trk_process_dev': [vp, vp, sz, vp],
         'gpsmi_trk_replay': [vp, vp, C.c_int, vp, vp, vp],
         'gpsmi_trk_replay_states': [vp, vp, sz],
+        'gpsmi_trk_replay_load': [vp, C.c_int, vp, vp],
+        'gpsmi_trk_replay_run': [vp, vp, C.c_int],
+        'gpsmi_trk_replay_fetch': [vp, vp, sz],
+        'gpsmi_host_alloc': [sz, P(vp)],
+        'gpsmi_host_free': [vp],
         'gpsmi_trk_last_ms': [vp, P(f32), P(f32)],
         'gpsmi_comm_unique_id': [vp],
         'gpsmi_comm_create': [vp, C.c_int, C.c_int, C.c_int, P(vp)],

@@ -99,6 +99,27 @@ class DeviceBuffer:
             pass
 
 
+class PinnedArray:
+    """numpy array over page-locked host memory (hipHostMalloc)."""
+
+    def __init__(self, shape, dtype):
+        self.lib = _lib.load()
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        p = C.c_void_p()
+        check(self.lib.gpsmi_host_alloc(max(n, 1), C.byref(p)),
+              'gpsmi_host_alloc')
+        self._p = p
+        buf = (C.c_char * n).from_address(p.value)
+        self.array = np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def free(self):
+        if self._p:
+            self.array = None
+            check(self.lib.gpsmi_host_free(self._p), 'gpsmi_host_free')
+            self._p = None
+
+
 def unpack_u8iq(d_out, d_raw, n, device=0):
     """raw uint16 (Q<<8|I) -> complex64 on the device (gpsrecv.py:170-172)."""
     check(_lib.load().gpsmi_dev_unpack_u8iq(device, d_out, d_raw, n),
@@ -236,6 +257,26 @@ class TrkEngine:
         check(self.lib.gpsmi_trk_replay(self.h, d_iq, nb, ptr(table),
                                         ptr(delay_used), ptr(out)),
               'gpsmi_trk_replay')
+        return out
+
+    def replay_load(self, nb, table, delay_used=None):
+        table = np.ascontiguousarray(table, dtype=STATE_DTYPE)
+        if table.shape != (nb, self.max_ch):
+            raise ValueError('table must be [nb, max_ch]')
+        if delay_used is not None:
+            delay_used = np.ascontiguousarray(delay_used, dtype=np.int32)
+        check(self.lib.gpsmi_trk_replay_load(self.h, nb, ptr(table),
+                                             ptr(delay_used)),
+              'gpsmi_trk_replay_load')
+
+    def replay_run(self, d_iq, nb):
+        check(self.lib.gpsmi_trk_replay_run(self.h, d_iq, nb),
+              'gpsmi_trk_replay_run')
+
+    def replay_fetch(self, out):
+        """out: C-contiguous OUT_DTYPE array (ideally from pinned_array)."""
+        check(self.lib.gpsmi_trk_replay_fetch(self.h, ptr(out), out.size),
+              'gpsmi_trk_replay_fetch')
         return out
 
     def replay_states(self, nb):

@@ -69,6 +69,9 @@ int gpsmi_dev_free(int device, void* dptr);
 int gpsmi_dev_upload(int device, void* dptr, const void* host, size_t bytes);
 int gpsmi_dev_download(int device, void* host, const void* dptr, size_t bytes);
 int gpsmi_dev_sync(int device);
+/* Page-locked host memory (hipHostMalloc) for full-rate transfers.            */
+int gpsmi_host_alloc(size_t bytes, void** hptr);
+int gpsmi_host_free(void* hptr);
 /* streamData's decode on the device (gpsrecv.py:168-173): raw uint16 (Q<<8|I)
  * -> complex64 (I + jQ)/127.5 - (1+1j); both pointers are device pointers.  */
 int gpsmi_dev_unpack_u8iq(int device, void* d_iq_c64, const void* d_raw_u16,
@@ -202,6 +205,15 @@ int gpsmi_trk_process_dev(gpsmi_trk* h, const void* d_iq, size_t n,
 int gpsmi_trk_replay(gpsmi_trk* h, const void* d_iq, int nb,
                      const gpsmi_trk_state* table, const int32_t* delay_used,
                      gpsmi_trk_out* out);
+/* The same in three steps, so that a caller can keep the table resident and
+ * time the device work alone: load uploads table (+ delay_used, may be NULL),
+ * run launches the kernels on nb device-resident blocks and waits for them,
+ * fetch downloads the [nb][nch] output records (out may be pinned memory from
+ * gpsmi_host_alloc for a full-rate copy).                                     */
+int gpsmi_trk_replay_load(gpsmi_trk* h, int nb, const gpsmi_trk_state* table,
+                          const int32_t* delay_used);
+int gpsmi_trk_replay_run(gpsmi_trk* h, const void* d_iq, int nb);
+int gpsmi_trk_replay_fetch(gpsmi_trk* h, gpsmi_trk_out* out, size_t n);
 /* State at the END of every job of the last replay, [nb][nch]: equals the next
  * row of the table when the table is a closed-loop trajectory.               */
 int gpsmi_trk_replay_states(gpsmi_trk* h, gpsmi_trk_state* states, size_t n);
