@@ -201,47 +201,11 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(
     }
 }
 
-// The correlator.  partial[job][i] = {sum over m < d, sum over m >= d} of
-// code[(m - d) mod cs] * wiped[i*cs + m], as two complex numbers.
-__global__ __launch_bounds__(256) void trk_dump_kernel(
-    const float2* __restrict__ iq, const gpsmi_trk_state* __restrict__ st_in,
-    const JobMid* __restrict__ mid, const float* __restrict__ t32,
-    const float* __restrict__ code, TrkParams P, float4* __restrict__ partial) {
-    __shared__ float red[16];
-    const int t = threadIdx.x, job = blockIdx.x, i = blockIdx.y;
-    if (!mid[job].active) return;
-    const gpsmi_trk_state& st = st_in[job];
-    const float2* blk = iq + (size_t)(job / P.nch) * ((size_t)P.cs * P.n_cyc);
-    const float om = st.omega0 != 0.f ? st.omega0 : omega_of(st.freq);
-    const float ph = st.phase;
-    const int d = mid[job].delay_used;
-    const float* c = code + (size_t)st.prn * kFftN;
-    float lo_r = 0.f, lo_i = 0.f, hi_r = 0.f, hi_i = 0.f;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        int m = t + 256 * r;
-        int k = i * kFftN + m;
-        float2 w = wipe(blk[k], ph, om, t32[k]);
-        float cv = c[(m - d) & (kFftN - 1)];
-        float yr = cv * w.x, yi = cv * w.y;
-        if (m < d) { lo_r += yr; lo_i += yi; } else { hi_r += yr; hi_i += yi; }
-    }
-    lo_r = wave_sum_t(lo_r); lo_i = wave_sum_t(lo_i);
-    hi_r = wave_sum_t(hi_r); hi_i = wave_sum_t(hi_i);
-    const int wave = t >> 6, lane = t & 63;
-    if (lane == 0) {
-        red[wave] = lo_r; red[4 + wave] = lo_i; red[8 + wave] = hi_r; red[12 + wave] = hi_i;
-    }
-    __syncthreads();
-    if (t == 0) {
-        float4 p;
-        p.x = (red[0] + red[1]) + (red[2] + red[3]);
-        p.y = (red[4] + red[5]) + (red[6] + red[7]);
-        p.z = (red[8] + red[9]) + (red[10] + red[11]);
-        p.w = (red[12] + red[13]) + (red[14] + red[15]);
-        partial[(size_t)job * P.n_cyc + i] = p;
-    }
-}
+}  // namespace gpsmi
+
+#include "gpsmi_trk_stream.h"
+
+namespace gpsmi {
 
 // np.mean of a float32 array of n <= 128 elements: numpy's pairwise kernel
 // (eight strided accumulators, tree-combined, tail added in order).
@@ -264,7 +228,7 @@ __device__ inline float np_sum_f32(const float* a, int n) {
 
 __global__ __launch_bounds__(64) void trk_epilogue_kernel(
     const gpsmi_trk_state* __restrict__ st_in, gpsmi_trk_state* __restrict__ st_out,
-    const JobMid* __restrict__ mid, const float4* __restrict__ partial, TrkParams P,
+    const JobMid* __restrict__ mid, const float2* __restrict__ partial, TrkParams P,
     int njobs, gpsmi_trk_out* __restrict__ out) {
     const int job = blockIdx.x * blockDim.x + threadIdx.x;
     if (job >= njobs) return;
@@ -276,7 +240,8 @@ __global__ __launch_bounds__(64) void trk_epilogue_kernel(
     gpsmi_trk_out& o = out[job];
     const int d = mid[job].delay_used;
     const int cs = P.cs, nc = P.n_cyc;
-    const float4* pp = partial + (size_t)job * nc;
+    // S[0] = head (m < d of row 0), S[q+1] = window q, S[nc] = tail (m >= d of the last row)
+    const float2* S = partial + (size_t)job * (nc + 1);
 
     // ---- prompt dumps: windows of decodeData (gpslib.py:1403-1420, :1440)
     float gr[GPSMI_MAX_DUMPS], gi[GPSMI_MAX_DUMPS];
@@ -284,28 +249,28 @@ __global__ __launch_bounds__(64) void trk_epilogue_kernel(
     int n1 = st.nps + d;
     float car_r = 0.f, car_i = 0.f;
     int nps_new = 0;
-    if (n1 == 0) {
+    if (n1 == 0) {                        // no carry, delay 0: the rows are the windows
         for (int i = 0; i < nc; ++i) {
-            gr[nd] = (pp[i].x + pp[i].z) / (float)cs;
-            gi[nd] = (pp[i].y + pp[i].w) / (float)cs;
+            gr[nd] = S[i + 1].x / (float)cs;
+            gi[nd] = S[i + 1].y / (float)cs;
             ++nd;
         }
         o.first_len = cs;
     } else {
-        gr[0] = (st.prev_sum_re + pp[0].x) / (float)n1;
-        gi[0] = (st.prev_sum_im + pp[0].y) / (float)n1;
+        gr[0] = (st.prev_sum_re + S[0].x) / (float)n1;
+        gi[0] = (st.prev_sum_im + S[0].y) / (float)n1;
         nd = 1;
         for (int j = 1; j < nc; ++j) {
-            gr[nd] = (pp[j - 1].z + pp[j].x) / (float)cs;
-            gi[nd] = (pp[j - 1].w + pp[j].y) / (float)cs;
+            gr[nd] = S[j].x / (float)cs;
+            gi[nd] = S[j].y / (float)cs;
             ++nd;
         }
         if (d == 0) {                     // the last code period is complete
-            gr[nd] = pp[nc - 1].z / (float)cs;
-            gi[nd] = pp[nc - 1].w / (float)cs;
+            gr[nd] = S[nc].x / (float)cs;
+            gi[nd] = S[nc].y / (float)cs;
             ++nd;
         } else {                          // carried into the next block
-            car_r = pp[nc - 1].z; car_i = pp[nc - 1].w;
+            car_r = S[nc].x; car_i = S[nc].y;
             nps_new = cs - d;
         }
         o.first_len = n1;
@@ -412,7 +377,7 @@ struct gpsmi_trk {
     gpsmi_trk_state* d_tab_out = nullptr;
     int* d_forced = nullptr;
     JobMid* d_mid = nullptr;
-    float4* d_partial = nullptr;
+    float2* d_partial = nullptr;
     gpsmi_trk_out* d_out = nullptr;
     float last_total_ms = 0.f, last_corr_ms = 0.f;
     int replay_nb = 0;
@@ -431,7 +396,7 @@ static int trk_reserve(gpsmi_trk* h, size_t njobs) {
     GPSMI_HIP(hipMalloc((void**)&h->d_tab_out, njobs * sizeof(gpsmi_trk_state)));
     GPSMI_HIP(hipMalloc((void**)&h->d_forced, njobs * sizeof(int)));
     GPSMI_HIP(hipMalloc((void**)&h->d_mid, njobs * sizeof(JobMid)));
-    GPSMI_HIP(hipMalloc((void**)&h->d_partial, njobs * h->cfg.n_cyc * sizeof(float4)));
+    GPSMI_HIP(hipMalloc((void**)&h->d_partial, njobs * (h->cfg.n_cyc + 1) * sizeof(float2)));
     GPSMI_HIP(hipMalloc((void**)&h->d_out, njobs * sizeof(gpsmi_trk_out)));
     h->njobs_cap = njobs;
     return GPSMI_OK;
@@ -448,8 +413,25 @@ static int trk_launch(gpsmi_trk* h, const float2* d_iq, const gpsmi_trk_state* s
     hipLaunchKernelGGL(trk_corr_kernel, dim3(njobs), dim3(256), 0, h->stream, d_iq, st_in, forced,
                        h->d_t32, h->d_rep, h->d_tw, P, h->d_out, h->d_mid);
     GPSMI_HIP(hipEventRecord(h->ev[1], h->stream));
-    hipLaunchKernelGGL(trk_dump_kernel, dim3(njobs, P.n_cyc), dim3(256), 0, h->stream, d_iq, st_in,
-                       h->d_mid, h->d_t32, h->d_code, P, h->d_partial);
+    {
+        const int nblocks = njobs / nch;
+        const int ngroups = (nch + kGroupCh - 1) / kGroupCh;
+        const dim3 grid(((nblocks + 7) / 8) * 8 * ngroups), block(kStreamThreads);
+        switch (P.n_cyc) {
+            case 32:
+                hipLaunchKernelGGL(trk_stream_kernel<32>, grid, block, 0, h->stream, d_iq, st_in,
+                                   h->d_mid, h->d_code, P, ngroups, nblocks, h->d_partial);
+                break;
+            case 16:
+                hipLaunchKernelGGL(trk_stream_kernel<16>, grid, block, 0, h->stream, d_iq, st_in,
+                                   h->d_mid, h->d_code, P, ngroups, nblocks, h->d_partial);
+                break;
+            default:
+                hipLaunchKernelGGL(trk_stream_kernel<8>, grid, block, 0, h->stream, d_iq, st_in,
+                                   h->d_mid, h->d_code, P, ngroups, nblocks, h->d_partial);
+                break;
+        }
+    }
     GPSMI_HIP(hipEventRecord(h->ev[2], h->stream));
     hipLaunchKernelGGL(trk_epilogue_kernel, dim3((njobs + 63) / 64), dim3(64), 0, h->stream, st_in,
                        st_out, h->d_mid, h->d_partial, P, njobs, h->d_out);
@@ -483,7 +465,8 @@ int gpsmi_trk_create(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk** out) {
     if (cfg->code_samples != kFftN)
         return fail(GPSMI_E_UNSUPPORTED, "tracking engine is built for code_samples = %d, got %d",
                     kFftN, cfg->code_samples);
-    GPSMI_REQUIRE(cfg->n_cyc >= 4 && cfg->n_cyc + 1 <= GPSMI_MAX_DUMPS, "n_cyc out of range 4..32");
+    GPSMI_REQUIRE(cfg->n_cyc == 8 || cfg->n_cyc == 16 || cfg->n_cyc == 32,
+                  "n_cyc must be 8, 16 or 32 (gpsglob.py:122)");
     GPSMI_REQUIRE(cfg->corr_avg >= 1, "corr_avg must be >= 1");
     GPSMI_REQUIRE(1024 / cfg->n_cyc <= GPSMI_MAX_DF, "n_cyc too small for the DF list");
     GPSMI_HIP(hipSetDevice(cfg->device));

@@ -1,0 +1,305 @@
+// The tracking correlator: carrier-NCO mix and prompt correlate-and-dump of a
+// whole 32-ms block for up to six channels per workgroup, every IQ sample
+// loaded once per workgroup and shared by its channels.
+//
+// Replaces decodeData's array arithmetic (reference src/gpslib.py:1400-1420):
+// y = roll(replica, delay) * (data * exp(-j(phase + 2 pi f t))), then sums of y
+// over code-period windows.  What makes it a streaming kernel:
+//
+//  * The carrier separates.  For sample k = r*CS + m (row r = code period,
+//    m = position in it):  phase + w (k+1)/fs = [phase + w (m+1)/fs] + w r T,
+//    T = CS/fs = 1 ms.  So  B[ch][m] = replica[(m - d) mod CS] * exp(-j theta_m)
+//    is computed once per (block, channel, m) and kept in registers, the inner
+//    loop is one complex multiply-accumulate per channel-sample, and the row
+//    factor U[r] = exp(-j w r T) is applied once per dump at the end.
+//  * Window q of the reference covers samples with m >= d of row q ("hi") and
+//    m < d of row q+1 ("lo").  B of a lo element carries one extra row rotation
+//    (theta_m + w T), so both parts of a window share U[q].
+//  * Lane mapping: wave w owns the 512 consecutive positions [512 w, 512 w+512),
+//    lane l the pairs m = 512 w + 128 i + 2 l + e (i < 4, e < 2): every load
+//    instruction of a wave reads 1 KiB contiguous, and for each channel all
+//    waves but the one containing d are purely hi or purely lo.  Pure waves
+//    accumulate acc[row] += B*x[row] (a lo wave's row r is window r-1, fixed up
+//    when the waves are combined); only the one mixed wave per channel selects
+//    between x[row] and x[row+1] per element.
+//  * Rows are processed in passes of 4 so that 6 channels x 4 accumulators fit
+//    in registers next to B (6 x 8 complex); after each pass the 64 lanes of a
+//    wave are summed through an LDS transpose (fixed order: deterministic).
+//
+// Output: partial[job][0] = head (lo part of row 0, joins the carry from the
+// previous block), partial[job][q+1] = window q (q = 0..NC-2), partial[job][NC]
+// = tail (hi part of the last row: a full window when d == 0, else the carry),
+// all multiplied by their U.  Algorithmic HBM traffic: 8 bytes per sample per
+// channel group.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace gpsmi {
+
+constexpr int kGroupCh = 6;        // channels per workgroup
+constexpr int kPassRows = 4;       // rows per accumulation pass
+constexpr int kStreamThreads = 256;
+constexpr int kJ = 8;              // code positions per lane
+constexpr int kTrVals = 2 * kGroupCh * kPassRows;            // 48 floats per lane and pass
+constexpr int kTrStride = kTrVals + 1;                       // + pad: conflict-free both ways
+
+struct StreamChan {
+    float om, ph;
+    int d, prn, job, active;
+};
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void cmac(float2& a, float2 b, float2 x) {
+    a.x = fmaf(b.x, x.x, a.x);
+    a.x = fmaf(-b.y, x.y, a.x);
+    a.y = fmaf(b.x, x.y, a.y);
+    a.y = fmaf(b.y, x.x, a.y);
+}
+
+// Two complex multiply-accumulates a0 += b0*x0, a1 += b1*x1 as four
+// v_pk_fma_f32 on (re, im) register pairs: op_sel picks the halves, neg_lo
+// supplies the minus sign of re -= b.im*x.im, so b stays one register pair
+// (hipcc's own packing keeps (b.re, b.re) and (-b.im, b.im) copies: 4 VGPRs per
+// element).  The two chains are interleaved and the block ends in s_nop, which
+// covers the one wait state gfx950 needs between a packed write and its reader.
+__device__ __forceinline__ void cmac2(v2f& a0, v2f& a1, v2f b0, v2f x0, v2f b1, v2f x1) {
+    asm("v_pk_fma_f32 %0, %2, %3, %0 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %1, %4, %5, %1 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"
+        "v_pk_fma_f32 %1, %4, %5, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"
+        "s_nop 0"
+        : "+v"(a0), "+v"(a1)
+        : "v"(b0), "v"(x0), "v"(b1), "v"(x1));
+}
+
+// (cos, -sin) of 2*pi*rev, i.e. exp(-j 2 pi rev), |error| ~ 1e-7.  Exact range
+// reduction in revolutions, octant polynomials (Cephes sinf/cosf coefficients).
+__device__ __forceinline__ float2 phasor_rev(float rev) {
+    const float f = rev - rintf(rev);                  // [-0.5, 0.5]
+    const float qf = rintf(4.0f * f);                  // -2 .. 2
+    const float z = (f - 0.25f * qf) * 6.28318530717958647692f;   // |z| <= pi/4
+    const float z2 = z * z;
+    float sn = fmaf(fmaf(fmaf(-1.9515295891e-4f, z2, 8.3321608736e-3f), z2, -1.6666654611e-1f),
+                    z2 * z, z);
+    float co = fmaf(fmaf(fmaf(2.443315711809948e-5f, z2, -1.388731625493765e-3f), z2,
+                         4.166664568298827e-2f), z2 * z2, fmaf(-0.5f, z2, 1.0f));
+    const int q = (int)qf & 3;
+    // rotate by q quarter turns: (c, s) -> (c cos - s sin ...)
+    float c = (q == 0) ? co : (q == 1) ? -sn : (q == 2) ? -co : sn;
+    float sg = (q == 0) ? sn : (q == 1) ? co : (q == 2) ? -sn : -co;
+    return make_float2(c, -sg);
+}
+
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b) {
+    return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
+}
+
+template <int NC>
+__global__ __launch_bounds__(kStreamThreads, 2) void trk_stream_kernel(
+    const float2* __restrict__ iq, const gpsmi_trk_state* __restrict__ st_in,
+    const JobMid* __restrict__ mid, const float* __restrict__ code, TrkParams P,
+    int ngroups, int nblocks, float2* __restrict__ partial) {
+    static_assert(NC % kPassRows == 0, "rows must be a multiple of the pass length");
+    __shared__ float tr[4][64][kTrStride];                    // per-wave transpose scratch
+    __shared__ float2 sw[4][kGroupCh][NC];                    // per-wave row sums
+    __shared__ int cls[4][kGroupCh];                          // 0 hi, 1 lo, 2 mixed
+    __shared__ float2 hd[4][kGroupCh];                        // head sums of the mixed waves
+    __shared__ StreamChan schan[kGroupCh];
+    __shared__ float2 rot[kGroupCh][kJ + 1];                  // exp(-j w off_j/fs), [kJ]: exp(-j w T)
+
+    // XCD-aware decode: the groups of one block run on one XCD, back to back
+    const int wg = blockIdx.x;
+    const int xcd = wg & 7, slot = wg >> 3;
+    const int g = slot % ngroups;
+    const int b = (slot / ngroups) * 8 + xcd;
+    if (b >= nblocks) return;
+
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int cs = kFftN;
+    const float2* blk = iq + (size_t)b * ((size_t)cs * NC);
+    const float inv_fs = 1.0f / (1000.0f * (float)cs);
+
+    // ---- per-channel set-up
+    // (a) wave-uniform rotation constants, one thread each, angles in double
+    const double inv_2pi = 0.15915494309189533576888376337251;
+    if (t < kGroupCh * (kJ + 1)) {
+        const int c = t / (kJ + 1), k = t % (kJ + 1);
+        const int cidx = g * kGroupCh + c;
+        float2 r = make_float2(1.f, 0.f);
+        const int job = b * P.nch + cidx;
+        if (cidx < P.nch && mid[job].active) {
+            const gpsmi_trk_state& st = st_in[job];
+            const float om = st.omega0 != 0.f ? st.omega0 : omega_of(st.freq);
+            const int off = (k == kJ) ? cs : 128 * (k >> 1) + (k & 1);
+            const double rev = (double)om * inv_2pi * (double)off / (1000.0 * (double)cs);
+            r = phasor_rev((float)(rev - rint(rev)));
+        }
+        rot[c][k] = r;
+    }
+    __syncthreads();
+    // (b) B in registers: one base phasor per channel and lane, the other seven
+    // positions by rotation; lo elements carry one extra row rotation
+    v2f B[kGroupCh][kJ];
+    unsigned lomask[kGroupCh];
+    int kcls[kGroupCh];
+    const int mbase = 512 * wave + 2 * lane;                  // m = mbase + 128 i + e
+#pragma unroll
+    for (int c = 0; c < kGroupCh; ++c) {
+        const int cidx = g * kGroupCh + c;
+        StreamChan s;
+        s.job = b * P.nch + cidx;
+        s.active = 0; s.om = 0.f; s.ph = 0.f; s.d = 0; s.prn = 0;
+        if (cidx < P.nch && mid[s.job].active) {
+            const gpsmi_trk_state& st = st_in[s.job];
+            s.active = 1;
+            s.om = st.omega0 != 0.f ? st.omega0 : omega_of(st.freq);
+            s.ph = st.phase;
+            s.d = mid[s.job].delay_used;
+            s.prn = st.prn;
+        }
+        if (t == 0) schan[c] = s;
+        // theta(mbase) in revolutions: ph/2pi + (om/2pi) (mbase+1)/fs
+        const float f_eff = (float)((double)s.om * inv_2pi);
+        const float rev0 = fmaf(f_eff, (float)(mbase + 1) * inv_fs, s.ph * (float)inv_2pi);
+        const float2 z0 = phasor_rev(rev0);
+        const float2 rT = rot[c][kJ];
+        unsigned lm = 0;
+        const float* cv = code + (size_t)s.prn * cs;
+#pragma unroll
+        for (int j = 0; j < kJ; ++j) {
+            const int m = mbase + 128 * (j >> 1) + (j & 1);
+            const bool lo = m < s.d;
+            lm |= (lo ? 1u : 0u) << j;
+            float2 z = (j == 0) ? z0 : cmulf(z0, rot[c][j]);
+            const float2 zl = cmulf(z, rT);
+            z = make_float2(lo ? zl.x : z.x, lo ? zl.y : z.y);
+            const float v = s.active ? cv[(m - s.d) & (cs - 1)] : 0.f;
+            B[c][j] = v2f{v * z.x, v * z.y};
+        }
+        lomask[c] = lm;
+        // wave-uniform class
+        const int w0 = 512 * wave;
+        int k = (s.d <= w0) ? 0 : (s.d >= w0 + 512 ? 1 : 2);
+        if (!s.active) k = 0;
+        k = __builtin_amdgcn_readfirstlane(k);
+        kcls[c] = k;
+        if (lane == 0) cls[wave][c] = k;
+    }
+
+    // ---- stream the rows
+    v2f xc[kJ], xn[kJ], xp[kJ];                                // row r, r+1, r+2
+    auto load_row = [&](v2f* dst, int r) {
+        if (r < NC) {
+            const float4* p = reinterpret_cast<const float4*>(blk + (size_t)r * cs + mbase);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float4 v = p[i * 64];                          // 128 samples = 64 float4 apart
+                dst[2 * i] = v2f{v.x, v.y};
+                dst[2 * i + 1] = v2f{v.z, v.w};
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kJ; ++j) dst[j] = v2f{0.f, 0.f};
+        }
+    };
+    load_row(xc, 0);
+    load_row(xn, 1);
+
+    // head: the lo part of row 0 belongs to window -1.  Pure lo waves get it by
+    // relabelling their row 0; the mixed wave adds it here.
+#pragma unroll
+    for (int c = 0; c < kGroupCh; ++c) {
+        float2 h = make_float2(0.f, 0.f);
+        if (kcls[c] == 2) {
+#pragma unroll
+            for (int j = 0; j < kJ; ++j)
+                if ((lomask[c] >> j) & 1u)
+                    cmac(h, make_float2(B[c][j].x, B[c][j].y), make_float2(xc[j].x, xc[j].y));
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                h.x += __shfl_down(h.x, o, 64);
+                h.y += __shfl_down(h.y, o, 64);
+            }
+        }
+        if (lane == 0) hd[wave][c] = h;
+    }
+
+#pragma unroll 1
+    for (int pass = 0; pass < NC / kPassRows; ++pass) {
+        v2f acc[kGroupCh][kPassRows];
+#pragma unroll
+        for (int c = 0; c < kGroupCh; ++c)
+#pragma unroll
+            for (int r = 0; r < kPassRows; ++r) acc[c][r] = v2f{0.f, 0.f};
+#pragma unroll
+        for (int rr = 0; rr < kPassRows; ++rr) {
+            const int r = pass * kPassRows + rr;
+            load_row(xp, r + 2);
+            // every channel, every element: acc[row] += B * x[row]
+#pragma unroll
+            for (int j = 0; j < kJ; ++j)
+#pragma unroll
+                for (int c = 0; c < kGroupCh; c += 2)
+                    cmac2(acc[c][rr], acc[c + 1][rr], B[c][j], xc[j], B[c + 1][j], xc[j]);
+            // the one mixed wave of a channel: its lo elements take row r+1 instead
+#pragma unroll
+            for (int c = 0; c < kGroupCh; ++c) {
+                if (kcls[c] == 2) {
+                    float2 a = make_float2(0.f, 0.f);
+                    unsigned lm = lomask[c];
+                    asm volatile("" : "+v"(lm));      // keep the masked B out of registers
+#pragma unroll
+                    for (int j = 0; j < kJ; ++j) {
+                        const bool lo = (lm >> j) & 1u;
+                        const float2 bl = make_float2(lo ? B[c][j].x : 0.f, lo ? B[c][j].y : 0.f);
+                        cmac(a, bl, make_float2(xn[j].x - xc[j].x, xn[j].y - xc[j].y));
+                    }
+                    acc[c][rr] += v2f{a.x, a.y};
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kJ; ++j) { xc[j] = xn[j]; xn[j] = xp[j]; }
+        }
+        // ---- sum over the 64 lanes of the wave: transpose through LDS
+        // (6 channels x 4 rows x re/im = 48 values per lane), fixed order
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < kTrVals; ++v) {
+            const int c = v / (2 * kPassRows), rr = (v % (2 * kPassRows)) / 2;
+            tr[wave][lane][v] = (v & 1) ? acc[c][rr].y : acc[c][rr].x;
+        }
+        __syncthreads();
+        if (lane < kTrVals) {
+            float s = 0.f;
+#pragma unroll 8
+            for (int l = 0; l < 64; ++l) s += tr[wave][l][lane];
+            const int c = lane / (2 * kPassRows), rr = (lane % (2 * kPassRows)) / 2;
+            float* dst = reinterpret_cast<float*>(&sw[wave][c][pass * kPassRows + rr]);
+            dst[lane & 1] = s;
+        }
+    }
+    __syncthreads();
+
+    // ---- combine the four waves (fixed order), apply U, write the partial sums
+    // out index o = q + 1, q = -1 .. NC-1.  A lo wave's row r is window r-1.
+    for (int item = t; item < kGroupCh * (NC + 1); item += kStreamThreads) {
+        const int c = item / (NC + 1), o = item % (NC + 1), q = o - 1;
+        const StreamChan s = schan[c];
+        if (!s.active) continue;
+        float sx = 0.f, sy = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int k = cls[w][c];
+            const int r = (k == 1) ? q + 1 : q;                // lo wave: row q+1 feeds window q
+            if (r >= 0 && r < NC) { sx += sw[w][c][r].x; sy += sw[w][c][r].y; }
+            if (q == -1 && k == 2) { sx += hd[w][c].x; sy += hd[w][c].y; }
+        }
+        // U[q] = exp(-j om q T), angle reduced in double (in revolutions)
+        const double rev = (double)s.om * 0.15915494309189533576888376337251 * (double)q * 1.0e-3;
+        const float2 u = phasor_rev((float)(rev - rint(rev)));          // (cos a, -sin a)
+        partial[(size_t)s.job * (NC + 1) + o] = make_float2(sx * u.x - sy * u.y, sy * u.x + sx * u.y);
+    }
+}
+
+}  // namespace gpsmi
