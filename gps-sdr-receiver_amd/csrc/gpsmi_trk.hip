@@ -5,21 +5,19 @@
 // loop runs the open channels of one block, replay runs nb x nch jobs at once
 // from a recorded state table.  Three kernels per call, in stream order:
 //
-//   trk_corr_kernel   one workgroup per job.  Carrier wipe-off of the centre
-//                     corr_avg code periods with the reference's float32 phase
-//                     argument (demodDoppler, :1343-1346), fold, 2048-point
-//                     FFT in LDS, x conj(replica spectrum), FFT again as the
-//                     inverse, |.|, mean / std / first argmax and the two
-//                     neighbours of the peak (cacodeCorr :1315-1327,
-//                     findCodePhase :1293-1304).  Thread 0 applies the
-//                     CORR_MIN threshold, fitCodePhase (:1268-1290) and picks
-//                     the DELAY the block is decoded with (:1181-1182).
-//   trk_dump_kernel   the correlator: one workgroup per (job, code period).
-//                     Carrier-NCO mix of the whole block times the replica
-//                     rolled by DELAY (decodeData :1400-1401), summed
-//                     separately before and after the code-period boundary so
-//                     that the epilogue can assemble the reference's windows
-//                     (:1408-1420), including the partial first window and the
+//   trk_corr_kernel   (gpsmi_trk_corr.h) one workgroup per (block, six
+//                     channels): carrier wipe-off and fold of the centre
+//                     corr_avg code periods (demodDoppler :1343-1346),
+//                     2048-point FFT in LDS, x conj(replica spectrum), FFT
+//                     again as the inverse, |.|, mean / std / first argmax and
+//                     the neighbours of the peak (cacodeCorr :1315-1327,
+//                     findCodePhase :1293-1304); CORR_MIN threshold,
+//                     fitCodePhase (:1268-1290) and the DELAY the block is
+//                     decoded with (:1181-1182).
+//   trk_stream_kernel (gpsmi_trk_stream.h) the correlator: carrier-NCO mix of
+//                     the whole block times the replica rolled by DELAY
+//                     (decodeData :1400-1401), summed per code-period window
+//                     (:1408-1420) including the partial first window and the
 //                     carry into the next block (:1403-1405, :1440).
 //   trk_epilogue_kernel  one thread per job: prompt dumps (means), amplitude
 //                     statistics (:1186-1188), phaseLockedLoop (:1215-1262) and
@@ -28,6 +26,7 @@
 // Loop-carried state lives in device memory; the closed loop needs no host
 // round trip between blocks.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -49,6 +48,7 @@ struct TrkParams {
     int df_no;         // 1024 / n_cyc
     float t_last;      // SEC_TIME[NGPS-1]
     float om_min, om_max;   // float32(2*pi*MIN_FREQ), float32(2*pi*MAX_FREQ) from float64
+    int flags;              // diagnostics only (GPSMI_DEBUG_FLAGS): 1 no MAC, 2 no lane sums, 4 no mixed fix
 };
 
 // per-job scratch between the kernels
@@ -97,113 +97,10 @@ __device__ inline double fit_code_phase(double lo, double pk, double hi, int mx)
     return (double)mx + 0.5 * (tri + par);
 }
 
-__global__ __launch_bounds__(256) void trk_corr_kernel(
-    const float2* __restrict__ iq, const gpsmi_trk_state* __restrict__ st_in,
-    const int* __restrict__ delay_forced, const float* __restrict__ t32,
-    const float2* __restrict__ rep, const float2* __restrict__ tw, TrkParams P,
-    gpsmi_trk_out* __restrict__ out, JobMid* __restrict__ mid) {
-    __shared__ float lds[kFftLdsFloats];
-    __shared__ float red[20];
-    const int t = threadIdx.x, job = blockIdx.x;
-    const gpsmi_trk_state& st = st_in[job];
-    if (st.prn <= 0) {
-        if (t == 0) { mid[job].active = 0; mid[job].delay_used = 0; out[job].prn = 0; }
-        return;
-    }
-    const float2* blk = iq + (size_t)(job / P.nch) * ((size_t)P.cs * P.n_cyc);
-    const float om = st.omega0 != 0.f ? st.omega0 : omega_of(st.freq);
-    const float ph = st.phase;
-    const int first = (P.n_cyc - P.corr_avg) / 2;
-    float2 v[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] = make_float2(0.f, 0.f);
-    for (int i = first; i < first + P.corr_avg; ++i) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            int k = i * kFftN + t + 256 * r;
-            float2 w = wipe(blk[k], ph, om, t32[k]);
-            v[r].x += w.x; v[r].y += w.y;
-        }
-    }
-    fft2048(v, lds, tw, t);
-    const float sc = 1.0f / (float)P.corr_avg;
-    const float2* R = rep + (size_t)st.prn * kFftN;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        float2 x = make_float2(v[q].x * sc, v[q].y * sc), r = R[t + 256 * q];
-        v[q] = make_float2(x.x * r.x + x.y * r.y, x.x * r.y - x.y * r.x);   // conj(x) * r
-    }
-    __syncthreads();                     // LDS buffer 0 is rewritten by the next FFT
-    fft2048(v, lds, tw, t);
-    float mag[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) mag[q] = sqrtf(v[q].x * v[q].x + v[q].y * v[q].y) * (1.0f / kFftN);
-
-    // mean / std / first-index argmax
-    const int wave = t >> 6, lane = t & 63;
-    float s = 0.f, bv = mag[0];
-    int bi = t;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        s += mag[q];
-        if (mag[q] > bv) { bv = mag[q]; bi = t + 256 * q; }
-    }
-    s = wave_sum_t(s);
-    wave_argmax_t(bv, bi);
-    if (lane == 0) { red[wave] = s; red[4 + wave] = bv; ((int*)red)[8 + wave] = bi; }
-    __syncthreads();
-    s = (red[0] + red[1]) + (red[2] + red[3]);
-    bv = red[4]; bi = ((int*)red)[8];
-#pragma unroll
-    for (int w = 1; w < 4; ++w) {
-        float ov = red[4 + w];
-        int oi = ((int*)red)[8 + w];
-        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-    }
-    const float mean = s * (1.0f / kFftN);
-    float d2 = 0.f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { float d = mag[q] - mean; d2 += d * d; }
-    d2 = wave_sum_t(d2);
-    if (lane == 0) red[12 + wave] = d2;
-    // neighbours of the peak, circular (fitCodePhase :1271-1272)
-    const int ia = (bi + kFftN - 1) & (kFftN - 1), ib = (bi + 1) & (kFftN - 1);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        if (t + 256 * q == ia) red[16] = mag[q];
-        if (t + 256 * q == ib) red[17] = mag[q];
-    }
-    __syncthreads();
-    if (t == 0) {
-        d2 = (red[12] + red[13]) + (red[14] + red[15]);
-        const float sd = sqrtf(d2 * (1.0f / kFftN));
-        const float norm = (bv - mean) / sd;
-        gpsmi_trk_out& o = out[job];
-        o.prn = st.prn;
-        o.mx = bi;
-        o.epl[0] = red[16]; o.epl[1] = bv; o.epl[2] = red[17];
-        o.corr_mean = mean; o.corr_std = sd;
-        o.norm_max_corr = norm;
-        int delay = -1;
-        double cp = -1.0;
-        if (norm > P.corr_min) {
-            delay = bi;
-            cp = fit_code_phase((double)red[16], (double)bv, (double)red[17], bi);
-        }
-        o.delay = delay;
-        o.reserved0 = 0;
-        o.code_phase = cp;
-        int used = delay >= 0 ? delay : st.delay;
-        if (delay_forced && delay_forced[job] >= 0) used = delay_forced[job];
-        o.delay_used = used;
-        mid[job].delay_used = used;
-        mid[job].active = 1;
-    }
-}
-
 }  // namespace gpsmi
 
 #include "gpsmi_trk_stream.h"
+#include "gpsmi_trk_corr.h"
 
 namespace gpsmi {
 
@@ -410,13 +307,14 @@ static int trk_launch(gpsmi_trk* h, const float2* d_iq, const gpsmi_trk_state* s
     // records of closed channels stay all-zero (prn = 0)
     GPSMI_HIP(hipMemsetAsync(h->d_out, 0, (size_t)njobs * sizeof(gpsmi_trk_out), h->stream));
     GPSMI_HIP(hipEventRecord(h->ev[0], h->stream));
-    hipLaunchKernelGGL(trk_corr_kernel, dim3(njobs), dim3(256), 0, h->stream, d_iq, st_in, forced,
-                       h->d_t32, h->d_rep, h->d_tw, P, h->d_out, h->d_mid);
+    const int nblocks = njobs / nch;
+    const int ngroups = (nch + kGroupCh - 1) / kGroupCh;
+    const dim3 sgrid(((nblocks + 7) / 8) * 8 * ngroups);
+    hipLaunchKernelGGL(trk_corr_kernel, sgrid, dim3(256), 0, h->stream, d_iq, st_in, forced, h->d_rep,
+                       h->d_tw, P, ngroups, nblocks, h->d_out, h->d_mid);
     GPSMI_HIP(hipEventRecord(h->ev[1], h->stream));
     {
-        const int nblocks = njobs / nch;
-        const int ngroups = (nch + kGroupCh - 1) / kGroupCh;
-        const dim3 grid(((nblocks + 7) / 8) * 8 * ngroups), block(kStreamThreads);
+        const dim3 grid = sgrid, block(kStreamThreads);
         switch (P.n_cyc) {
             case 32:
                 hipLaunchKernelGGL(trk_stream_kernel<32>, grid, block, 0, h->stream, d_iq, st_in,
@@ -500,6 +398,8 @@ int gpsmi_trk_create(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk** out) {
     P.nch = max_ch; P.df_no = 1024 / cfg->n_cyc; P.t_last = t32[ngps - 1];
     P.om_min = (float)(2.0 * M_PI * (double)cfg->min_freq);
     P.om_max = (float)(2.0 * M_PI * (double)cfg->max_freq);
+    const char* dbg = getenv("GPSMI_DEBUG_FLAGS");
+    P.flags = dbg ? atoi(dbg) : 0;
     return trk_reserve(h, max_ch);
 }
 

@@ -1,0 +1,193 @@
+// Code-phase correlation of the tracking loop: cacodeCorr + findCodePhase +
+// fitCodePhase (reference src/gpslib.py:1315-1327, :1293-1304, :1268-1290) for
+// up to six channels of one block per workgroup.
+//
+// The reference wipes the carrier off the centre corr_avg code periods, sums
+// their FFTs, multiplies by conj(FFT(replica)) and takes |ifft|.  Here the sum
+// of FFTs is the FFT of the sum, and the wipe-off separates exactly as in the
+// correlator (gpsmi_trk_stream.h): for sample k = i*CS + m
+//     exp(-j(phase + w (k+1)/fs)) = V(m) * U[i],  U[i] = exp(-j w i T),
+// so fold[m] = V(m) * sum_i U[i] x[i][m]: one complex multiply-accumulate per
+// channel-sample with a wave-uniform U, every sample loaded once for the six
+// channels; V is applied once per position.  Then, per channel, two passes of
+// the LDS-resident 2048-point FFT (the second one as the inverse), |.|, mean /
+// population std / first-index argmax, the two neighbours of the peak, and
+// thread 0 applies the CORR_MIN threshold, the peak fit and chooses the DELAY
+// the block is decoded with (gpslib.py:1181-1182).
+#pragma once
+#include "gpsmi_fft.h"
+
+namespace gpsmi {
+
+__global__ __launch_bounds__(256) void trk_corr_kernel(
+    const float2* __restrict__ iq, const gpsmi_trk_state* __restrict__ st_in,
+    const int* __restrict__ delay_forced, const float2* __restrict__ rep,
+    const float2* __restrict__ tw, TrkParams P, int ngroups, int nblocks,
+    gpsmi_trk_out* __restrict__ out, JobMid* __restrict__ mid) {
+    __shared__ float lds[kFftLdsFloats];
+    __shared__ float red[20];
+    __shared__ float2 urow[kGroupCh][32];              // U[c][i], i = row
+    __shared__ float2 step[kGroupCh];                  // exp(-j w 256/fs)
+    __shared__ StreamChan schan[kGroupCh];
+
+    const int wg = blockIdx.x;
+    const int xcd = wg & 7, slot = wg >> 3;
+    const int g = slot % ngroups;
+    const int b = (slot / ngroups) * 8 + xcd;
+    if (b >= nblocks) return;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int cs = kFftN;
+    const float2* blk = iq + (size_t)b * ((size_t)cs * P.n_cyc);
+    const double inv_2pi = 0.15915494309189533576888376337251;
+    const int first = (P.n_cyc - P.corr_avg) / 2;
+
+    // ---- per-channel constants (one thread each), then one barrier
+    if (t < kGroupCh * 33) {
+        const int c = t / 33, i = t % 33;
+        const int cidx = g * kGroupCh + c;
+        const int job = b * P.nch + cidx;
+        StreamChan s;
+        s.job = job; s.active = 0; s.om = 0.f; s.ph = 0.f; s.d = 0; s.prn = 0;
+        if (cidx < P.nch && st_in[job].prn > 0) {
+            const gpsmi_trk_state& st = st_in[job];
+            s.active = 1;
+            s.om = st.omega0 != 0.f ? st.omega0 : omega_of(st.freq);
+            s.ph = st.phase;
+            s.d = st.delay;
+            s.prn = st.prn;
+        }
+        const double f_eff = (double)s.om * inv_2pi;
+        if (i < 32) {
+            const double rev = f_eff * (double)i * 1.0e-3;            // w i T / 2 pi
+            urow[c][i] = phasor_rev((float)(rev - rint(rev)));
+        } else {
+            const double rev = f_eff * 256.0 / (1000.0 * (double)cs);
+            step[c] = phasor_rev((float)(rev - rint(rev)));
+            schan[c] = s;
+            if (cidx < P.nch && !s.active) {                          // closed channel
+                mid[job].active = 0; mid[job].delay_used = 0;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- fold: acc[c][r] = sum_i U[c][i] x[i][t + 256 r]
+    v2f acc[kGroupCh][8];
+#pragma unroll
+    for (int c = 0; c < kGroupCh; ++c)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc[c][r] = v2f{0.f, 0.f};
+    for (int i = first; i < first + P.corr_avg; ++i) {
+        v2f x[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float2 v = blk[(size_t)i * cs + t + 256 * r];
+            x[r] = v2f{v.x, v.y};
+        }
+        v2f u[kGroupCh];
+#pragma unroll
+        for (int c = 0; c < kGroupCh; ++c) u[c] = v2f{urow[c][i].x, urow[c][i].y};
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int c = 0; c < kGroupCh; c += 2)
+                cmac2(acc[c][r], acc[c + 1][r], u[c], x[r], u[c + 1], x[r]);
+    }
+
+    // ---- per channel: apply V, FFT, x conj(R), FFT, statistics
+    const float inv_fs = 1.0f / (1000.0f * (float)cs);
+    const float sc = 1.0f / (float)P.corr_avg;
+#pragma unroll
+    for (int c = 0; c < kGroupCh; ++c) {
+        const StreamChan s = schan[c];
+        if (!s.active) continue;                                      // uniform over the workgroup
+        // V(m) for m = t + 256 r: base phasor and seven steps of 256 positions
+        const float f_eff = (float)((double)s.om * inv_2pi);
+        const float rev0 = fmaf(f_eff, (float)(t + 1) * inv_fs, s.ph * (float)inv_2pi);
+        float2 vm = phasor_rev(rev0);
+        const float2 st256 = step[c];
+        float2 v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float2 a = make_float2(acc[c][r].x * sc, acc[c][r].y * sc);
+            v[r] = cmulf(a, vm);
+            vm = cmulf(vm, st256);
+        }
+        __syncthreads();                       // LDS of the previous channel's FFT is free
+        fft2048(v, lds, tw, t);
+        const float2* R = rep + (size_t)s.prn * kFftN;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float2 x = v[q], r = R[t + 256 * q];
+            v[q] = make_float2(x.x * r.x + x.y * r.y, x.x * r.y - x.y * r.x);   // conj(x) * r
+        }
+        __syncthreads();
+        fft2048(v, lds, tw, t);
+        float mag[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            mag[q] = sqrtf(v[q].x * v[q].x + v[q].y * v[q].y) * (1.0f / kFftN);
+
+        // mean / std / first-index argmax over the 2048 lags
+        float sm = 0.f, bv = mag[0];
+        int bi = t;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            sm += mag[q];
+            if (mag[q] > bv) { bv = mag[q]; bi = t + 256 * q; }
+        }
+        sm = wave_sum_t(sm);
+        wave_argmax_t(bv, bi);
+        __syncthreads();                       // red[] of the previous channel is consumed
+        if (lane == 0) { red[wave] = sm; red[4 + wave] = bv; ((int*)red)[8 + wave] = bi; }
+        __syncthreads();
+        sm = (red[0] + red[1]) + (red[2] + red[3]);
+        bv = red[4]; bi = ((int*)red)[8];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float ov = red[4 + w];
+            const int oi = ((int*)red)[8 + w];
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        const float mean = sm * (1.0f / kFftN);
+        float d2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const float d = mag[q] - mean; d2 += d * d; }
+        d2 = wave_sum_t(d2);
+        if (lane == 0) red[12 + wave] = d2;
+        const int ia = (bi + kFftN - 1) & (kFftN - 1), ib = (bi + 1) & (kFftN - 1);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (t + 256 * q == ia) red[16] = mag[q];
+            if (t + 256 * q == ib) red[17] = mag[q];
+        }
+        __syncthreads();
+        if (t == 0) {
+            d2 = (red[12] + red[13]) + (red[14] + red[15]);
+            const float sd = sqrtf(d2 * (1.0f / kFftN));
+            const float norm = (bv - mean) / sd;
+            gpsmi_trk_out& o = out[s.job];
+            o.prn = s.prn;
+            o.mx = bi;
+            o.epl[0] = red[16]; o.epl[1] = bv; o.epl[2] = red[17];
+            o.corr_mean = mean; o.corr_std = sd;
+            o.norm_max_corr = norm;
+            int delay = -1;
+            double cp = -1.0;
+            if (norm > P.corr_min) {
+                delay = bi;
+                cp = fit_code_phase((double)red[16], (double)bv, (double)red[17], bi);
+            }
+            o.delay = delay;
+            o.reserved0 = 0;
+            o.code_phase = cp;
+            int used = delay >= 0 ? delay : s.d;
+            if (delay_forced && delay_forced[s.job] >= 0) used = delay_forced[s.job];
+            o.delay_used = used;
+            mid[s.job].delay_used = used;
+            mid[s.job].active = 1;
+        }
+    }
+}
+
+}  // namespace gpsmi

@@ -95,12 +95,37 @@ __device__ __forceinline__ float2 cmulf(float2 a, float2 b) {
     return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
 }
 
+// d = lane-mask ? x : 0 on a register pair, the 64-bit mask held in SGPRs
+__device__ __forceinline__ v2f mask_pair(v2f x, unsigned long long m) {
+    v2f d;
+    asm("v_cndmask_b32_e64 %0, 0, %2, %4\n\t"
+        "v_cndmask_b32_e64 %1, 0, %3, %4"
+        : "=&v"(d.x), "=&v"(d.y)
+        : "v"(x.x), "v"(x.y), "s"(m));
+    return d;
+}
+
+// Correction of the one mixed wave of a channel for one row: its lo elements
+// belong to the window of the row above, i.e. they must see x[r+1] instead of
+// x[r]; the plain pass already added B*x[r], so add B*(x[r+1]-x[r]) for them.
+// Chunks (128 positions, two elements per lane) below the boundary chunk IS are
+// lo in every lane; chunk IS is lo where the ballot masks say so.
+template <int IS>
+__device__ __forceinline__ void mixed_fix(v2f& acc, const v2f* B, const v2f* df,
+                                          unsigned long long m0, unsigned long long m1) {
+    v2f t0 = v2f{0.f, 0.f}, t1 = v2f{0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < IS; ++i) cmac2(t0, t1, B[2 * i], df[2 * i], B[2 * i + 1], df[2 * i + 1]);
+    cmac2(t0, t1, B[2 * IS], mask_pair(df[2 * IS], m0), B[2 * IS + 1], mask_pair(df[2 * IS + 1], m1));
+    acc += t0 + t1;
+}
+
 template <int NC>
 __global__ __launch_bounds__(kStreamThreads, 2) void trk_stream_kernel(
     const float2* __restrict__ iq, const gpsmi_trk_state* __restrict__ st_in,
     const JobMid* __restrict__ mid, const float* __restrict__ code, TrkParams P,
     int ngroups, int nblocks, float2* __restrict__ partial) {
-    static_assert(NC % kPassRows == 0, "rows must be a multiple of the pass length");
+    static_assert(NC % kPassRows == 0 && kPassRows == 4, "the row ring assumes passes of four rows");
     __shared__ float tr[4][64][kTrStride];                    // per-wave transpose scratch
     __shared__ float2 sw[4][kGroupCh][NC];                    // per-wave row sums
     __shared__ int cls[4][kGroupCh];                          // 0 hi, 1 lo, 2 mixed
@@ -141,8 +166,8 @@ __global__ __launch_bounds__(kStreamThreads, 2) void trk_stream_kernel(
     // (b) B in registers: one base phasor per channel and lane, the other seven
     // positions by rotation; lo elements carry one extra row rotation
     v2f B[kGroupCh][kJ];
-    unsigned lomask[kGroupCh];
-    int kcls[kGroupCh];
+    int kcls[kGroupCh], istar[kGroupCh];
+    unsigned long long lm0[kGroupCh], lm1[kGroupCh];
     const int mbase = 512 * wave + 2 * lane;                  // m = mbase + 128 i + e
 #pragma unroll
     for (int c = 0; c < kGroupCh; ++c) {
@@ -162,33 +187,50 @@ __global__ __launch_bounds__(kStreamThreads, 2) void trk_stream_kernel(
         // theta(mbase) in revolutions: ph/2pi + (om/2pi) (mbase+1)/fs
         const float f_eff = (float)((double)s.om * inv_2pi);
         const float rev0 = fmaf(f_eff, (float)(mbase + 1) * inv_fs, s.ph * (float)inv_2pi);
-        const float2 z0 = phasor_rev(rev0);
+        float2 z0 = phasor_rev(rev0);
         const float2 rT = rot[c][kJ];
-        unsigned lm = 0;
-        const float* cv = code + (size_t)s.prn * cs;
-#pragma unroll
-        for (int j = 0; j < kJ; ++j) {
-            const int m = mbase + 128 * (j >> 1) + (j & 1);
-            const bool lo = m < s.d;
-            lm |= (lo ? 1u : 0u) << j;
-            float2 z = (j == 0) ? z0 : cmulf(z0, rot[c][j]);
-            const float2 zl = cmulf(z, rT);
-            z = make_float2(lo ? zl.x : z.x, lo ? zl.y : z.y);
-            const float v = s.active ? cv[(m - s.d) & (cs - 1)] : 0.f;
-            B[c][j] = v2f{v * z.x, v * z.y};
-        }
-        lomask[c] = lm;
-        // wave-uniform class
+        // wave-uniform class: 0 all hi (m >= d), 1 all lo, 2 mixed
         const int w0 = 512 * wave;
         int k = (s.d <= w0) ? 0 : (s.d >= w0 + 512 ? 1 : 2);
         if (!s.active) k = 0;
         k = __builtin_amdgcn_readfirstlane(k);
         kcls[c] = k;
         if (lane == 0) cls[wave][c] = k;
+        if (k == 1) z0 = cmulf(z0, rT);                       // every element is lo
+        const float* cv = code + (size_t)s.prn * cs;
+#pragma unroll
+        for (int j = 0; j < kJ; ++j) {
+            const int m = mbase + 128 * (j >> 1) + (j & 1);
+            float2 z = (j == 0) ? z0 : cmulf(z0, rot[c][j]);
+            if (k == 2) {                                     // only the mixed wave decides per element
+                const float2 zl = cmulf(z, rT);
+                const bool lo = m < s.d;
+                z = make_float2(lo ? zl.x : z.x, lo ? zl.y : z.y);
+            }
+            const float v = s.active ? cv[(m - s.d) & (cs - 1)] : 0.f;
+            B[c][j] = v2f{v * z.x, v * z.y};
+        }
+        // mixed wave: boundary chunk and the lane masks of its two elements
+        int is = 0;
+        unsigned long long b0 = 0, b1 = 0;
+        if (k == 2) {
+            is = (s.d - w0 - 1) >> 7;                          // chunk holding m = d-1
+            b0 = __ballot(w0 + 128 * is + 2 * lane < s.d);
+            b1 = __ballot(w0 + 128 * is + 2 * lane + 1 < s.d);
+        }
+        istar[c] = __builtin_amdgcn_readfirstlane(is);
+        lm0[c] = b0;
+        lm1[c] = b1;
     }
+    int anymixed = 0;
+#pragma unroll
+    for (int c = 0; c < kGroupCh; ++c) anymixed |= (kcls[c] == 2);
 
     // ---- stream the rows
-    v2f xc[kJ], xn[kJ], xp[kJ];                                // row r, r+1, r+2
+    // ring of four row buffers with static roles: row r lives in xb[r & 3]; while
+    // row r is processed, row r+3 is loaded into the buffer row r-1 just left
+    // (prefetch distance three rows, no register copies)
+    v2f xb[4][kJ];
     auto load_row = [&](v2f* dst, int r) {
         if (r < NC) {
             const float4* p = reinterpret_cast<const float4*>(blk + (size_t)r * cs + mbase);
@@ -203,26 +245,29 @@ __global__ __launch_bounds__(kStreamThreads, 2) void trk_stream_kernel(
             for (int j = 0; j < kJ; ++j) dst[j] = v2f{0.f, 0.f};
         }
     };
-    load_row(xc, 0);
-    load_row(xn, 1);
+    load_row(xb[0], 0);
+    load_row(xb[1], 1);
+    load_row(xb[2], 2);
 
     // head: the lo part of row 0 belongs to window -1.  Pure lo waves get it by
     // relabelling their row 0; the mixed wave adds it here.
 #pragma unroll
     for (int c = 0; c < kGroupCh; ++c) {
-        float2 h = make_float2(0.f, 0.f);
+        v2f h = v2f{0.f, 0.f};
         if (kcls[c] == 2) {
-#pragma unroll
-            for (int j = 0; j < kJ; ++j)
-                if ((lomask[c] >> j) & 1u)
-                    cmac(h, make_float2(B[c][j].x, B[c][j].y), make_float2(xc[j].x, xc[j].y));
+            switch (istar[c]) {
+                case 0: mixed_fix<0>(h, B[c], xb[0], lm0[c], lm1[c]); break;
+                case 1: mixed_fix<1>(h, B[c], xb[0], lm0[c], lm1[c]); break;
+                case 2: mixed_fix<2>(h, B[c], xb[0], lm0[c], lm1[c]); break;
+                default: mixed_fix<3>(h, B[c], xb[0], lm0[c], lm1[c]); break;
+            }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 h.x += __shfl_down(h.x, o, 64);
                 h.y += __shfl_down(h.y, o, 64);
             }
         }
-        if (lane == 0) hd[wave][c] = h;
+        if (lane == 0) hd[wave][c] = make_float2(h.x, h.y);
     }
 
 #pragma unroll 1
@@ -235,41 +280,64 @@ __global__ __launch_bounds__(kStreamThreads, 2) void trk_stream_kernel(
 #pragma unroll
         for (int rr = 0; rr < kPassRows; ++rr) {
             const int r = pass * kPassRows + rr;
-            load_row(xp, r + 2);
+            v2f* xc = xb[rr & 3];
+            v2f* xn = xb[(rr + 1) & 3];
+            load_row(xb[(rr + 3) & 3], r + 3);
             // every channel, every element: acc[row] += B * x[row]
+            if (!(P.flags & 1)) {
 #pragma unroll
-            for (int j = 0; j < kJ; ++j)
+                for (int j = 0; j < kJ; ++j)
 #pragma unroll
-                for (int c = 0; c < kGroupCh; c += 2)
-                    cmac2(acc[c][rr], acc[c + 1][rr], B[c][j], xc[j], B[c + 1][j], xc[j]);
+                    for (int c = 0; c < kGroupCh; c += 2)
+                        cmac2(acc[c][rr], acc[c + 1][rr], B[c][j], xc[j], B[c + 1][j], xc[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < kJ; ++j) asm volatile("" ::"v"(xc[j]));
+                acc[0][rr] += xc[0];
+            }
             // the one mixed wave of a channel: its lo elements take row r+1 instead
+            if (anymixed && !(P.flags & 4)) {
+                v2f df[kJ];
 #pragma unroll
-            for (int c = 0; c < kGroupCh; ++c) {
-                if (kcls[c] == 2) {
-                    float2 a = make_float2(0.f, 0.f);
-                    unsigned lm = lomask[c];
-                    asm volatile("" : "+v"(lm));      // keep the masked B out of registers
+                for (int j = 0; j < kJ; ++j) df[j] = xn[j] - xc[j];
 #pragma unroll
-                    for (int j = 0; j < kJ; ++j) {
-                        const bool lo = (lm >> j) & 1u;
-                        const float2 bl = make_float2(lo ? B[c][j].x : 0.f, lo ? B[c][j].y : 0.f);
-                        cmac(a, bl, make_float2(xn[j].x - xc[j].x, xn[j].y - xc[j].y));
+                for (int c = 0; c < kGroupCh; ++c) {
+                    if (kcls[c] == 2) {
+                        switch (istar[c]) {
+                            case 0: mixed_fix<0>(acc[c][rr], B[c], df, lm0[c], lm1[c]); break;
+                            case 1: mixed_fix<1>(acc[c][rr], B[c], df, lm0[c], lm1[c]); break;
+                            case 2: mixed_fix<2>(acc[c][rr], B[c], df, lm0[c], lm1[c]); break;
+                            default: mixed_fix<3>(acc[c][rr], B[c], df, lm0[c], lm1[c]); break;
+                        }
                     }
-                    acc[c][rr] += v2f{a.x, a.y};
                 }
             }
-#pragma unroll
-            for (int j = 0; j < kJ; ++j) { xc[j] = xn[j]; xn[j] = xp[j]; }
         }
         // ---- sum over the 64 lanes of the wave: transpose through LDS
         // (6 channels x 4 rows x re/im = 48 values per lane), fixed order
-        __syncthreads();
+        if (P.flags & 2) {
+            if (lane < kTrVals) {
+                const int c = lane / (2 * kPassRows), rr = (lane % (2 * kPassRows)) / 2;
+                float sacc = 0.f;
+#pragma unroll
+                for (int cc = 0; cc < kGroupCh; ++cc)
+#pragma unroll
+                    for (int r2 = 0; r2 < kPassRows; ++r2) sacc += acc[cc][r2].x + acc[cc][r2].y;
+                reinterpret_cast<float*>(&sw[wave][c][pass * kPassRows + rr])[lane & 1] = sacc;
+            }
+            continue;
+        }
+        // The scratch is private to the wave and the LDS unit executes one wave's
+        // instructions in order, so no workgroup barrier is needed here -- and none
+        // is wanted: __syncthreads() would also wait for vmcnt(0) and drain the
+        // three rows of loads in flight.
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int v = 0; v < kTrVals; ++v) {
             const int c = v / (2 * kPassRows), rr = (v % (2 * kPassRows)) / 2;
             tr[wave][lane][v] = (v & 1) ? acc[c][rr].y : acc[c][rr].x;
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
         if (lane < kTrVals) {
             float s = 0.f;
 #pragma unroll 8

@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 counter_collection.csv files: mean counter value per
+kernel (short name) over its dispatches."""
+import csv
+import glob
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+acc = defaultdict(lambda: defaultdict(list))
+for f in sorted(glob.glob(root + '/**/*counter_collection.csv', recursive=True)):
+    for row in csv.DictReader(open(f)):
+        k = row['Kernel_Name'].split('(')[0].replace('gpsmi::', '')
+        if 'stream' not in k and 'corr' not in k and 'epilogue' not in k:
+            continue
+        acc[k][row['Counter_Name']].append(float(row['Counter_Value']))
+for k, d in acc.items():
+    print(k)
+    for c, v in sorted(d.items()):
+        print(f'   {c:28s} {sum(v) / len(v):16.1f}  (n={len(v)})')
