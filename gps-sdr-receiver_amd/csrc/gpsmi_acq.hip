@@ -112,9 +112,10 @@ __global__ __launch_bounds__(256) void acq_spectrum_kernel(
 __global__ __launch_bounds__(256) void acq_corr_kernel(
     const float2* __restrict__ spectra, const float2* __restrict__ rep,
     const int* __restrict__ slot, gpsmi_peak* __restrict__ out, int nsv,
-    const float2* __restrict__ tw) {
+    const float2* __restrict__ tw, float2* __restrict__ nbr) {
     __shared__ float lds[kFftLdsFloats];
     __shared__ float red[16];
+    __shared__ float nb2[2];
     const int t = threadIdx.x, sv = blockIdx.x, bin = blockIdx.y;
     const float2* X = spectra + (size_t)bin * kFftN;
     const float2* R = rep + (size_t)slot[sv] * kFftN;
@@ -130,6 +131,16 @@ __global__ __launch_bounds__(256) void acq_corr_kernel(
     for (int q = 0; q < 8; ++q) mag[q] = sqrtf(v[q].x * v[q].x + v[q].y * v[q].y) * (1.0f / kFftN);
     int amax; float peak, mean, sd;
     corr_stats(mag, t, red, amax, peak, mean, sd);
+    if (nbr) {                                  // neighbours of the peak, circular
+        const int ia = (amax + kFftN - 1) & (kFftN - 1), ib = (amax + 1) & (kFftN - 1);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (t + 256 * q == ia) nb2[0] = mag[q];
+            if (t + 256 * q == ib) nb2[1] = mag[q];
+        }
+        __syncthreads();
+        if (t == 0) nbr[(size_t)bin * nsv + sv] = make_float2(nb2[0], nb2[1]);
+    }
     if (t == 0) {
         // fft(conj Y)[n] = conj(N ifft(Y)[n]): same lag index, no reversal
         gpsmi_peak p; p.argmax = amax; p.peak = peak; p.mean = mean; p.std = sd;
@@ -153,6 +164,7 @@ struct gpsmi_acq {
     float2* d_spec = nullptr; size_t spec_cap = 0;   // bins
     float* d_omega = nullptr; int* d_slot = nullptr; gpsmi_peak* d_peaks = nullptr;
     size_t cell_cap = 0;
+    float2* d_nbr = nullptr;
     float last_ms = 0.f;
 };
 
@@ -168,8 +180,10 @@ static int acq_reserve(gpsmi_acq* h, int nbins, int nsv) {
     size_t cells = (size_t)nbins * nsv;
     if (cells > h->cell_cap) {
         if (h->d_peaks) GPSMI_HIP(hipFree(h->d_peaks));
-        h->d_peaks = nullptr; h->cell_cap = 0;
+        if (h->d_nbr) GPSMI_HIP(hipFree(h->d_nbr));
+        h->d_peaks = nullptr; h->d_nbr = nullptr; h->cell_cap = 0;
         GPSMI_HIP(hipMalloc((void**)&h->d_peaks, cells * sizeof(gpsmi_peak)));
+        GPSMI_HIP(hipMalloc((void**)&h->d_nbr, cells * sizeof(float2)));
         h->cell_cap = cells;
     }
     return GPSMI_OK;
@@ -212,7 +226,7 @@ int gpsmi_acq_destroy(gpsmi_acq* h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* bufs[] = {h->d_tw, h->d_t32, h->d_rep, h->d_iq, h->d_spec, h->d_omega, h->d_slot,
-                    h->d_peaks};
+                    h->d_peaks, h->d_nbr};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -232,9 +246,9 @@ int gpsmi_acq_set_replica(gpsmi_acq* h, int prn, const float* spectrum) {
     return GPSMI_OK;
 }
 
-int gpsmi_acq_search_dev(gpsmi_acq* h, const void* d_iq, size_t n, const int32_t* prn, int nsv,
-                         const double* freqs, int nbins, int n_avg, gpsmi_peak* out,
-                         void* out_dev) {
+static int acq_search_impl(gpsmi_acq* h, const void* d_iq, size_t n, const int32_t* prn, int nsv,
+                           const double* freqs, int nbins, int n_avg, gpsmi_peak* out,
+                           void* out_dev, float* nbr) {
     GPSMI_REQUIRE(h && d_iq && prn && freqs, "null argument");
     GPSMI_REQUIRE(out || out_dev, "no output requested");
     GPSMI_REQUIRE(nsv >= 0 && nsv <= GPSMI_MAX_PRN, "nsv out of range");
@@ -260,7 +274,7 @@ int gpsmi_acq_search_dev(gpsmi_acq* h, const void* d_iq, size_t n, const int32_t
     hipLaunchKernelGGL(acq_spectrum_kernel, dim3(nbins), dim3(256), 0, h->stream,
                        (const float2*)d_iq, h->d_t32, h->d_omega, n_avg, h->d_spec, h->d_tw);
     hipLaunchKernelGGL(acq_corr_kernel, dim3(nsv, nbins), dim3(256), 0, h->stream, h->d_spec,
-                       h->d_rep, h->d_slot, h->d_peaks, nsv, h->d_tw);
+                       h->d_rep, h->d_slot, h->d_peaks, nsv, h->d_tw, nbr ? h->d_nbr : nullptr);
     GPSMI_HIP(hipGetLastError());
     GPSMI_HIP(hipEventRecord(h->ev1, h->stream));
     size_t bytes = (size_t)nbins * nsv * sizeof(gpsmi_peak);
@@ -268,13 +282,27 @@ int gpsmi_acq_search_dev(gpsmi_acq* h, const void* d_iq, size_t n, const int32_t
         GPSMI_HIP(hipMemcpyAsync(out_dev, h->d_peaks, bytes, hipMemcpyDeviceToDevice, h->stream));
     if (out)
         GPSMI_HIP(hipMemcpyAsync(out, h->d_peaks, bytes, hipMemcpyDeviceToHost, h->stream));
+    if (nbr)
+        GPSMI_HIP(hipMemcpyAsync(nbr, h->d_nbr, (size_t)nbins * nsv * sizeof(float2),
+                                 hipMemcpyDeviceToHost, h->stream));
     GPSMI_HIP(hipStreamSynchronize(h->stream));
     GPSMI_HIP(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
     return GPSMI_OK;
 }
 
+int gpsmi_acq_search_dev(gpsmi_acq* h, const void* d_iq, size_t n, const int32_t* prn, int nsv,
+                         const double* freqs, int nbins, int n_avg, gpsmi_peak* out,
+                         void* out_dev) {
+    return acq_search_impl(h, d_iq, n, prn, nsv, freqs, nbins, n_avg, out, out_dev, nullptr);
+}
+
 int gpsmi_acq_search(gpsmi_acq* h, const float* iq, size_t n, const int32_t* prn, int nsv,
                      const double* freqs, int nbins, int n_avg, gpsmi_peak* out) {
+    return gpsmi_acq_search_ex(h, iq, n, prn, nsv, freqs, nbins, n_avg, out, nullptr);
+}
+
+int gpsmi_acq_search_ex(gpsmi_acq* h, const float* iq, size_t n, const int32_t* prn, int nsv,
+                        const double* freqs, int nbins, int n_avg, gpsmi_peak* out, float* nbr) {
     GPSMI_REQUIRE(h && iq && out, "null argument");
     GPSMI_REQUIRE(n_avg >= 1 && n_avg <= h->cfg.n_cyc, "n_avg out of range 1..n_cyc");
     GPSMI_REQUIRE(n >= (size_t)n_avg * kFftN, "iq shorter than n_avg code periods");
@@ -287,7 +315,7 @@ int gpsmi_acq_search(gpsmi_acq* h, const float* iq, size_t n, const int32_t* prn
         h->iq_cap = need;
     }
     GPSMI_HIP(hipMemcpyAsync(h->d_iq, iq, need * sizeof(float2), hipMemcpyHostToDevice, h->stream));
-    return gpsmi_acq_search_dev(h, h->d_iq, need, prn, nsv, freqs, nbins, n_avg, out, nullptr);
+    return acq_search_impl(h, h->d_iq, need, prn, nsv, freqs, nbins, n_avg, out, nullptr, nbr);
 }
 
 int gpsmi_acq_last_ms(gpsmi_acq* h, float* ms) {

@@ -59,7 +59,8 @@ EXPORTS = [
     'gpsmi_host_alloc', 'gpsmi_host_free',
     'gpsmi_dev_unpack_u8iq',
     'gpsmi_acq_create', 'gpsmi_acq_destroy', 'gpsmi_acq_set_replica',
-    'gpsmi_acq_search', 'gpsmi_acq_search_dev', 'gpsmi_acq_last_ms',
+    'gpsmi_acq_search', 'gpsmi_acq_search_dev', 'gpsmi_acq_search_ex',
+    'gpsmi_acq_last_ms',
     'gpsmi_trk_create', 'gpsmi_trk_destroy', 'gpsmi_trk_set_replica',
     'gpsmi_trk_open', 'gpsmi_trk_close', 'gpsmi_trk_get_state',
     'gpsmi_trk_set_state', 'gpsmi_trk_erase_prev', 'gpsmi_trk_process',
@@ -107,6 +108,8 @@ def load():
         'gpsmi_acq_search': [vp, vp, sz, vp, C.c_int, vp, C.c_int, C.c_int, vp],
         'gpsmi_acq_search_dev': [vp, vp, sz, vp, C.c_int, vp, C.c_int, C.c_int,
                                  vp, vp],
+        'gpsmi_acq_search_ex': [vp, vp, sz, vp, C.c_int, vp, C.c_int, C.c_int, vp,
+                                vp],
         'gpsmi_acq_last_ms': [vp, P(f32)],
         'gpsmi_trk_create': [P(Cfg), C.c_int, P(vp)],
         'gpsmi_trk_destroy': [vp],

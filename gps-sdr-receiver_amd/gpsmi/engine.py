@@ -169,6 +169,18 @@ class AcqEngine:
                 len(f_a), n_avg, ptr(out)), 'gpsmi_acq_search')
         return out
 
+    def search_ex(self, iq, prns, freqs, n_avg):
+        """search() plus corr[argmax-1], corr[argmax+1] per cell: (table, nbr)."""
+        prn_a = np.ascontiguousarray(prns, dtype=np.int32)
+        f_a = np.ascontiguousarray(freqs, dtype=np.float64)
+        out = np.zeros((len(f_a), len(prn_a)), dtype=PEAK_DTYPE)
+        nbr = np.zeros((len(f_a), len(prn_a), 2), dtype=np.float32)
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        check(self.lib.gpsmi_acq_search_ex(
+            self.h, ptr(iq), iq.size, ptr(prn_a), len(prn_a), ptr(f_a), len(f_a),
+            n_avg, ptr(out), ptr(nbr)), 'gpsmi_acq_search_ex')
+        return out, nbr
+
     def last_ms(self):
         ms = C.c_float(0)
         check(self.lib.gpsmi_acq_last_ms(self.h, C.byref(ms)))

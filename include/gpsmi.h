@@ -113,6 +113,15 @@ int gpsmi_acq_search_dev(gpsmi_acq* h, const void* d_iq, size_t n,
                          const int32_t* prn, int nsv,
                          const double* freqs_hz, int nbins, int n_avg,
                          gpsmi_peak* out, void* out_dev);
+/* As gpsmi_acq_search, plus the two circular neighbours of every peak,
+ * nbr[(b*nsv + s)*2 + {0,1}] = corr[argmax-1], corr[argmax+1]: what
+ * fitCodePhase (gpslib.py:1268-1290) needs when a channel re-acquires through
+ * sweepFrequency / getCorrMax (gpslib.py:1350-1380).  first_period selects the
+ * code period the n_avg periods start at (getCorrMax uses 0).                 */
+int gpsmi_acq_search_ex(gpsmi_acq* h, const float* iq, size_t n,
+                        const int32_t* prn, int nsv,
+                        const double* freqs_hz, int nbins, int n_avg,
+                        gpsmi_peak* out, float* nbr);
 /* Timing of the last search on the handle's stream (HIP events), ms.          */
 int gpsmi_acq_last_ms(gpsmi_acq* h, float* ms);
 

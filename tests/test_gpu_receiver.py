@@ -1,0 +1,112 @@
+"""GPU: the worker-pool mirror (gpsmi.receiver: initMultiProcPool /
+initPoolStreams / satCalc / delPoolStreams, reference gpsrecv.py:340-417) driven
+like processData drives the reference, against the reference fixture."""
+import numpy as np
+import pytest
+
+from conftest import scene_blocks
+
+pytestmark = pytest.mark.gpu
+
+
+def test_pool_flow_matches_reference(golden_default):
+    from gpsmi import receiver as R
+    g = golden_default
+    nch, nb = g['trk_delay'].shape
+    found = [tuple(r) for r in g['sweep_found']]
+    found = [(n, int(s), f, int(d)) for n, s, f, d in found]
+    pool, pool_no, worker = R.initMultiProcPool(nch)
+    act = set()
+    new = {s for _, s, _, _ in found[:nch]}
+    worker, act = R.initPoolStreams(pool, pool_no, worker, act, set(new), found)
+    assert act == new and sorted(worker) == sorted(new)
+    init_sv = [int(s) for s in g['trk_init'][:, 0]]
+    blocks = scene_blocks('default', 5, nb)
+    co_ph = {s: [] for s in act}
+    for i in range(nb):
+        smp = np.int64((5 + i + 1) * 65536)
+        res = R.satCalc(act, pool, worker, blocks[i], smp)
+        assert len(res) == nch
+        for sw, sat, frames, cp, (cq, cl) in res:
+            c = init_sv.index(sat)
+            assert not sw
+            ref_cp = g['trk_code_phase'][c, i]
+            if ref_cp < 0:
+                assert cp == -1.0
+            else:
+                assert abs(cp - ref_cp) < 2e-3
+            assert float(cq) == g['trk_corr_q'][c, i]
+            assert float(cl) == g['trk_corr_l'][c, i]
+            hc = pool.chan[worker.index(sat)]
+            assert hc.MS_TIME == g['trk_ms_time'][c, i], (c, i)
+            assert len(hc.EDGES) == g['trk_n_edges'][c, i], (c, i)
+            if (smp // 65536) % 32 == 0:
+                assert len(frames) == 1 and frames[0]['SAT'] == sat
+                assert abs(frames[0]['FRQ'] - g['trk_freq'][c, i - 1]) < 0.05
+                assert abs(frames[0]['AMP'] - g['trk_amplitude'][c, i]) < 2e-2
+            else:
+                assert frames == []
+            co_ph[sat].append(cp)
+    # drop two satellites, as getNewSats would ask
+    drop = set(list(act)[:2])
+    worker, act = R.delPoolStreams(pool, pool_no, worker, act, drop)
+    assert len(act) == nch - 2 and worker.count(0) == 2
+    res = R.satCalc(act, pool, worker, blocks[0], np.int64((5 + nb + 1) * 65536))
+    assert {r[1] for r in res} == act
+    R.closeMultiProcPool(pool)
+
+
+def test_stream_gap_resets_carry(golden_default):
+    """gpslib.py:1143-1146: a skipped stream erases PREV_SAMPLES and the edges."""
+    from gpsmi import receiver as R
+    g = golden_default
+    sv, f0, d0 = g['trk_init'][0]
+    found = [(20.0, int(sv), float(f0), int(d0))]
+    pool, n, worker = R.initMultiProcPool(1)
+    worker, act = R.initPoolStreams(pool, n, worker, set(), {int(sv)}, found)
+    blocks = scene_blocks('default', 5, 3)
+    R.satCalc(act, pool, worker, blocks[0], np.int64(6 * 65536))
+    assert pool.trk.get_state(0)['nps'] > 0
+    # next call skips one stream number
+    R.satCalc(act, pool, worker, blocks[2], np.int64(8 * 65536))
+    hc = pool.chan[0]
+    assert hc.PREV_STREAM_NO == 8
+    rec_first_len = pool.trk.get_state(0)['nps']
+    assert rec_first_len == 2048 - pool.trk.get_state(0)['delay']
+    R.closeMultiProcPool(pool)
+
+
+def test_resweep_reacquires_a_lost_channel(golden_default):
+    """gpslib.py:1153-1173 + :1350-1380: a channel put into SWEEP finds its
+    satellite again through the acquisition engine and returns to tracking."""
+    from gpsmi import receiver as R
+    g = golden_default
+    sv, f0, d0 = g['trk_init'][0]
+    found = [(20.0, int(sv), float(f0), int(d0))]
+    pool, n, worker = R.initMultiProcPool(1)
+    worker, act = R.initPoolStreams(pool, n, worker, set(), {int(sv)}, found)
+    blocks = scene_blocks('default', 5, 6)
+    R.satCalc(act, pool, worker, blocks[0], np.int64(6 * 65536))
+    hc = pool.chan[0]
+    # force the sweep trigger the way initSweep leaves the channel
+    st = pool.trk.get_state(0)
+    hc.setPhaseUnlocked()
+    hc.FREQ_SAVE, hc.DF_SAVE = st['freq'], [0.0]
+    hc.FREQ = pool.cfg.min_freq
+    hc.SWEEP = True
+    pool.trk.close_channel(0)
+    sweeps = []
+    for i in range(1, 4):
+        res = R.satCalc(act, pool, worker, blocks[i], np.int64((6 + i) * 65536))
+        sweeps.append(res[0][0])
+        if not res[0][0]:
+            break
+    assert sweeps[-1] is False and len(sweeps) >= 2        # 40 bins per block from -5000 Hz
+    assert abs(hc.FREQ - f0) <= 200.0
+    assert abs(hc.DELAY - g['trk_delay'][0, len(sweeps)]) <= 2
+    assert res[0][3] >= 0                                  # fitted code phase
+    st = pool.trk.get_state(0)
+    assert st['prn'] == int(sv) and st['delay'] == hc.DELAY
+    res = R.satCalc(act, pool, worker, blocks[4], np.int64(10 * 65536))
+    assert res[0][0] is False and res[0][3] >= 0           # tracking again
+    R.closeMultiProcPool(pool)
