@@ -48,13 +48,18 @@ struct TrkParams {
     int df_no;         // 1024 / n_cyc
     float t_last;      // SEC_TIME[NGPS-1]
     float om_min, om_max;   // float32(2*pi*MIN_FREQ), float32(2*pi*MAX_FREQ) from float64
-    int flags;              // diagnostics only (GPSMI_DEBUG_FLAGS): 1 no MAC, 2 no lane sums, 4 no mixed fix
+    int flags;              // diagnostics only (GPSMI_DEBUG_FLAGS): 1 no MAC, 2 no lane sums, 4 no mixed fix, 8 LDS-ring correlator
 };
 
-// per-job scratch between the kernels
-struct JobMid {
+// per-job descriptor handed from the correlation kernel to the correlator and
+// the epilogue: everything the correlator's set-up needs in one 32-byte load
+struct __attribute__((aligned(32))) JobMid {
     int delay_used;    // DELAY the block is decoded with
     int active;
+    int prn;
+    float om;          // 2*pi*FREQ as the reference forms it
+    float ph;          // PHASE at the start of the block
+    int pad[3];
 };
 
 __device__ __forceinline__ float wave_sum_t(float v) {
@@ -100,6 +105,7 @@ __device__ inline double fit_code_phase(double lo, double pk, double hi, int mx)
 }  // namespace gpsmi
 
 #include "gpsmi_trk_stream.h"
+#include "gpsmi_trk_stream_lds.h"
 #include "gpsmi_trk_corr.h"
 
 namespace gpsmi {
@@ -313,7 +319,7 @@ static int trk_launch(gpsmi_trk* h, const float2* d_iq, const gpsmi_trk_state* s
     hipLaunchKernelGGL(trk_corr_kernel, sgrid, dim3(256), 0, h->stream, d_iq, st_in, forced, h->d_rep,
                        h->d_tw, P, ngroups, nblocks, h->d_out, h->d_mid);
     GPSMI_HIP(hipEventRecord(h->ev[1], h->stream));
-    {
+    if (!(P.flags & 8)) {                  // default: the register-staged correlator
         const dim3 grid = sgrid, block(kStreamThreads);
         switch (P.n_cyc) {
             case 32:
@@ -329,6 +335,23 @@ static int trk_launch(gpsmi_trk* h, const float2* d_iq, const gpsmi_trk_state* s
                                    h->d_mid, h->d_code, P, ngroups, nblocks, h->d_partial);
                 break;
         }
+    } else {                               // GPSMI_DEBUG_FLAGS=8: the LDS-ring variant
+#define GPSMI_LAUNCH_LDS(NC, G)                                                                 \
+    hipLaunchKernelGGL((trk_stream_lds_kernel<NC, G>), dim3(nblocks* nsuper), dim3(256 * G), 0, \
+                       h->stream, d_iq, st_in, h->d_mid, h->d_code, P, nsuper, nblocks,          \
+                       h->d_partial)
+        const int G = nch > kGroupCh ? 2 : 1;
+        const int nsuper = (nch + kGroupCh * G - 1) / (kGroupCh * G);
+        if (G == 2) {
+            if (P.n_cyc == 32) GPSMI_LAUNCH_LDS(32, 2);
+            else if (P.n_cyc == 16) GPSMI_LAUNCH_LDS(16, 2);
+            else GPSMI_LAUNCH_LDS(8, 2);
+        } else {
+            if (P.n_cyc == 32) GPSMI_LAUNCH_LDS(32, 1);
+            else if (P.n_cyc == 16) GPSMI_LAUNCH_LDS(16, 1);
+            else GPSMI_LAUNCH_LDS(8, 1);
+        }
+#undef GPSMI_LAUNCH_LDS
     }
     GPSMI_HIP(hipEventRecord(h->ev[2], h->stream));
     hipLaunchKernelGGL(trk_epilogue_kernel, dim3((njobs + 63) / 64), dim3(64), 0, h->stream, st_in,

@@ -65,7 +65,10 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(
             step[c] = phasor_rev((float)(rev - rint(rev)));
             schan[c] = s;
             if (cidx < P.nch && !s.active) {                          // closed channel
-                mid[job].active = 0; mid[job].delay_used = 0;
+                JobMid z;
+                z.delay_used = 0; z.active = 0; z.prn = 0; z.om = 0.f; z.ph = 0.f;
+                z.pad[0] = z.pad[1] = z.pad[2] = 0;
+                mid[job] = z;
             }
         }
     }
@@ -184,8 +187,10 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(
             int used = delay >= 0 ? delay : s.d;
             if (delay_forced && delay_forced[s.job] >= 0) used = delay_forced[s.job];
             o.delay_used = used;
-            mid[s.job].delay_used = used;
-            mid[s.job].active = 1;
+            JobMid md;
+            md.delay_used = used; md.active = 1; md.prn = s.prn; md.om = s.om; md.ph = s.ph;
+            md.pad[0] = md.pad[1] = md.pad[2] = 0;
+            mid[s.job] = md;
         }
     }
 }

@@ -152,12 +152,10 @@ __global__ __launch_bounds__(kStreamThreads, 2) void trk_stream_kernel(
         const int c = t / (kJ + 1), k = t % (kJ + 1);
         const int cidx = g * kGroupCh + c;
         float2 r = make_float2(1.f, 0.f);
-        const int job = b * P.nch + cidx;
-        if (cidx < P.nch && mid[job].active) {
-            const gpsmi_trk_state& st = st_in[job];
-            const float om = st.omega0 != 0.f ? st.omega0 : omega_of(st.freq);
+        const JobMid md = mid[b * P.nch + (cidx < P.nch ? cidx : P.nch - 1)];
+        if (cidx < P.nch && md.active) {
             const int off = (k == kJ) ? cs : 128 * (k >> 1) + (k & 1);
-            const double rev = (double)om * inv_2pi * (double)off / (1000.0 * (double)cs);
+            const double rev = (double)md.om * inv_2pi * (double)off / (1000.0 * (double)cs);
             r = phasor_rev((float)(rev - rint(rev)));
         }
         rot[c][k] = r;
@@ -172,17 +170,11 @@ __global__ __launch_bounds__(kStreamThreads, 2) void trk_stream_kernel(
 #pragma unroll
     for (int c = 0; c < kGroupCh; ++c) {
         const int cidx = g * kGroupCh + c;
+        const JobMid md = mid[b * P.nch + (cidx < P.nch ? cidx : P.nch - 1)];
         StreamChan s;
         s.job = b * P.nch + cidx;
-        s.active = 0; s.om = 0.f; s.ph = 0.f; s.d = 0; s.prn = 0;
-        if (cidx < P.nch && mid[s.job].active) {
-            const gpsmi_trk_state& st = st_in[s.job];
-            s.active = 1;
-            s.om = st.omega0 != 0.f ? st.omega0 : omega_of(st.freq);
-            s.ph = st.phase;
-            s.d = mid[s.job].delay_used;
-            s.prn = st.prn;
-        }
+        s.active = (cidx < P.nch) && md.active;
+        s.om = md.om; s.ph = md.ph; s.d = md.delay_used; s.prn = md.prn;
         if (t == 0) schan[c] = s;
         // theta(mbase) in revolutions: ph/2pi + (om/2pi) (mbase+1)/fs
         const float f_eff = (float)((double)s.om * inv_2pi);

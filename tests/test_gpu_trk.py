@@ -195,3 +195,25 @@ def test_channel_management_and_errors():
     eng.close_channel(1)
     assert eng.get_state(1)['prn'] == 0
     eng.close()
+
+
+def test_lds_ring_correlator_variant_agrees(closed_loop, monkeypatch):
+    """The LDS-ring form of the correlator (GPSMI_DEBUG_FLAGS=8, kept for A/B
+    work) computes the same windows as the default register-staged kernel; only
+    the summation order over lanes differs."""
+    from gpsmi.engine import TrkEngine, DeviceBuffer
+    _, outs, states, blocks = closed_loop
+    nb, nch = 8, outs.shape[1]
+    monkeypatch.setenv('GPSMI_DEBUG_FLAGS', '8')
+    eng = TrkEngine(max_ch=nch)
+    monkeypatch.delenv('GPSMI_DEBUG_FLAGS')
+    buf = DeviceBuffer(nb * blocks[0].nbytes)
+    for i in range(nb):
+        buf.upload(blocks[i], i * blocks[i].nbytes)
+    rep = eng.replay(buf.ptr, nb, states[:nb], outs['delay_used'][:nb])
+    buf.free()
+    eng.close()
+    for k in ('mx', 'delay', 'delay_used', 'n_dumps', 'nps', 'phase_locked'):
+        assert np.array_equal(rep[k], outs[:nb][k]), k
+    np.testing.assert_allclose(rep['dumps'], outs[:nb]['dumps'], rtol=2e-5, atol=2e-7)
+    np.testing.assert_allclose(rep['freq'], outs[:nb]['freq'], atol=1e-3)
