@@ -84,7 +84,9 @@ __global__ __launch_bounds__(256) void acq_spectrum_kernel(
     const float* __restrict__ omega, int n_avg, float2* __restrict__ spectra,
     const float2* __restrict__ tw) {
     __shared__ float lds[kFftLdsFloats];
+    __shared__ float lds_tw[kFftTwFloats];
     const int t = threadIdx.x, bin = blockIdx.x;
+    const FftTw ftw = fft_setup(lds_tw, tw, t);
     const float om = omega[bin];
     float2 v[8];
 #pragma unroll
@@ -102,7 +104,8 @@ __global__ __launch_bounds__(256) void acq_spectrum_kernel(
             v[r].y += c * x.y - s * x.x;
         }
     }
-    fft2048(v, lds, tw, t);
+    __syncthreads();
+    fft2048(v, lds, ftw, t);
     const float sc = 1.0f / (float)n_avg;
     float2* out = spectra + (size_t)bin * kFftN;
 #pragma unroll
@@ -116,7 +119,9 @@ __global__ __launch_bounds__(256) void acq_corr_kernel(
     __shared__ float lds[kFftLdsFloats];
     __shared__ float red[16];
     __shared__ float nb2[2];
+    __shared__ float lds_tw[kFftTwFloats];
     const int t = threadIdx.x, sv = blockIdx.x, bin = blockIdx.y;
+    const FftTw ftw = fft_setup(lds_tw, tw, t);
     const float2* X = spectra + (size_t)bin * kFftN;
     const float2* R = rep + (size_t)slot[sv] * kFftN;
     float2 v[8];
@@ -125,7 +130,8 @@ __global__ __launch_bounds__(256) void acq_corr_kernel(
         float2 x = X[t + 256 * q], r = R[t + 256 * q];
         v[q] = make_float2(x.x * r.x + x.y * r.y, x.x * r.y - x.y * r.x);   // conj(x) * r
     }
-    fft2048(v, lds, tw, t);
+    __syncthreads();
+    fft2048(v, lds, ftw, t);
     float mag[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) mag[q] = sqrtf(v[q].x * v[q].x + v[q].y * v[q].y) * (1.0f / kFftN);

@@ -17,10 +17,17 @@ namespace gpsmi {
 
 constexpr int kFftN = 2048;
 constexpr int kFftThreads = 256;
-constexpr int kFftPlane = kFftN + kFftN / 32;         // padded plane, floats
-constexpr int kFftLdsFloats = 4 * kFftPlane;          // two buffers x (re, im)
+constexpr int kFftPlane = kFftN + kFftN / 32;         // buffer 0 plane, floats
+constexpr int kFftPlane1 = kFftN + 8 * (kFftN / 64);  // buffer 1 plane, floats
+constexpr int kFftLdsFloats = 2 * kFftPlane + 2 * kFftPlane1;   // two buffers x (re, im)
 
+// Buffer 0 takes the stride-8 scatter of pass 1 (8 t + r) and the unit-stride
+// scatter of pass 3: one pad word per 32 makes both and the gathers
+// conflict-free.  Buffer 1 takes the scatter of pass 2 (64 (t/8) + t%8 + 8 r):
+// eight pad words per 64 spread the four 64-blocks of a half-wave over all 32
+// banks, and the unit-stride gather stays conflict-free.
 __device__ __forceinline__ int fft_pad(int i) { return i + (i >> 5); }
+__device__ __forceinline__ int fft_pad1(int i) { return i + 8 * (i >> 6); }
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
@@ -61,13 +68,41 @@ __device__ __forceinline__ void dft8(float2* v) {
     v[1] = a4; v[3] = a5; v[5] = a6; v[7] = a7;
 }
 
-// tw[k] = exp(-2 pi i k / 2048), k = 0..2047 (global memory, L1/L2 resident)
-__device__ __forceinline__ void fft2048(float2* v, float* lds, const float2* __restrict__ tw,
-                                        int t) {
+// Twiddles of one thread.  Passes 2 and 3 need 64th / 512th roots indexed by
+// r*(t mod 8) and r*(t mod 64): two compact LDS tables (64 + 512 entries, reads
+// at small strides, no global-memory latency inside a transform).  Pass 4 needs
+// six values that depend on the thread only: registers, loaded once per kernel.
+constexpr int kFftTwFloats = 2 * (64 + 512);          // LDS floats for the two tables
+struct FftTw {
+    const float2* t64;       // LDS: exp(-2 pi i k / 64),  k = 0..63
+    const float2* t512;      // LDS: exp(-2 pi i k / 512), k = 0..511
+    float2 w4[2][3];         // exp(-2 pi i r (t + 256 b) / 2048), r = 1..3
+};
+
+// tw[k] = exp(-2 pi i k / 2048) in global memory; lds_tw: kFftTwFloats floats.
+// Call once per kernel by all 256 threads, then __syncthreads() before the
+// first transform.
+__device__ __forceinline__ FftTw fft_setup(float* lds_tw, const float2* __restrict__ tw, int t) {
+    float2* t64 = reinterpret_cast<float2*>(lds_tw);
+    float2* t512 = t64 + 64;
+    if (t < 64) t64[t] = tw[32 * t];
+    t512[t] = tw[4 * t];
+    t512[t + 256] = tw[4 * (t + 256)];
+    FftTw f;
+    f.t64 = t64;
+    f.t512 = t512;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 1; r <= 3; ++r) f.w4[b][r - 1] = tw[r * (t + 256 * b)];
+    return f;
+}
+
+__device__ __forceinline__ void fft2048(float2* v, float* lds, const FftTw& tw, int t) {
     float* re0 = lds;
     float* im0 = lds + kFftPlane;
     float* re1 = lds + 2 * kFftPlane;
-    float* im1 = lds + 3 * kFftPlane;
+    float* im1 = lds + 2 * kFftPlane + kFftPlane1;
 
     // pass 1: Ns = 1, no twiddles; out index 8 t + r
     dft8(v);
@@ -86,26 +121,26 @@ __device__ __forceinline__ void fft2048(float2* v, float* lds, const float2* __r
     {
         int k = t & 7;
 #pragma unroll
-        for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], tw[32 * r * k]);
+        for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], tw.t64[r * k]);
         dft8(v);
         int base = (t >> 3) * 64 + k;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            int p = fft_pad(base + 8 * r);
+            int p = fft_pad1(base + 8 * r);
             re1[p] = v[r].x; im1[p] = v[r].y;
         }
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-        int p = fft_pad(t + 256 * r);
+        int p = fft_pad1(t + 256 * r);
         v[r] = make_float2(re1[p], im1[p]);
     }
     // pass 3: Ns = 64, twiddle exp(-2 pi i r k / 512), out (t/64)*512 + k + 64 r
     {
         int k = t & 63;
 #pragma unroll
-        for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], tw[4 * r * k]);
+        for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], tw.t512[r * k]);
         dft8(v);
         int base = (t >> 6) * 512 + k;
 #pragma unroll
@@ -124,10 +159,9 @@ __device__ __forceinline__ void fft2048(float2* v, float* lds, const float2* __r
     // inputs z[j + 512 r] = v[b + 2 r], outputs X[j + 512 r] -> same slots.
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-        int k = t + 256 * b;
-        float2 z1 = cmul(v[b + 2], tw[k]);
-        float2 z2 = cmul(v[b + 4], tw[2 * k]);
-        float2 z3 = cmul(v[b + 6], tw[3 * k]);
+        float2 z1 = cmul(v[b + 2], tw.w4[b][0]);
+        float2 z2 = cmul(v[b + 4], tw.w4[b][1]);
+        float2 z3 = cmul(v[b + 6], tw.w4[b][2]);
         float2 z0 = v[b];
         dft4(z0, z1, z2, z3);
         v[b] = z0; v[b + 2] = z1; v[b + 4] = z2; v[b + 6] = z3;

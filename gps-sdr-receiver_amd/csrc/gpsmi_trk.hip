@@ -19,9 +19,9 @@
 //                     (decodeData :1400-1401), summed per code-period window
 //                     (:1408-1420) including the partial first window and the
 //                     carry into the next block (:1403-1405, :1440).
-//   trk_epilogue_kernel  one thread per job: prompt dumps (means), amplitude
-//                     statistics (:1186-1188), phaseLockedLoop (:1215-1262) and
-//                     the state update (:1178, :1205-1208).
+//   trk_epilogue_kernel  one wave per job, lane = prompt dump: window means,
+//                     amplitude statistics (:1186-1188), phaseLockedLoop
+//                     (:1215-1262) and the state update (:1178, :1205-1208).
 //
 // Loop-carried state lives in device memory; the closed loop needs no host
 // round trip between blocks.
@@ -129,130 +129,146 @@ __device__ inline float np_sum_f32(const float* a, int n) {
     return res;
 }
 
-__global__ __launch_bounds__(64) void trk_epilogue_kernel(
+// One wave per job, lane i = prompt dump i.  Element-wise work (windows, |g|,
+// atan, phase unwrapping by a lane prefix sum) is spread over the lanes; the
+// few float32 sums are evaluated redundantly by every lane over small LDS
+// arrays in numpy's own order (np_sum_f32), so the result does not depend on
+// how lanes are scheduled.
+__global__ __launch_bounds__(256) void trk_epilogue_kernel(
     const gpsmi_trk_state* __restrict__ st_in, gpsmi_trk_state* __restrict__ st_out,
     const JobMid* __restrict__ mid, const float2* __restrict__ partial, TrkParams P,
     int njobs, gpsmi_trk_out* __restrict__ out) {
-    const int job = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float s_mag[4][40], s_dev[4][40], s_real[4][40], s_df[4][GPSMI_MAX_DF];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int job = blockIdx.x * 4 + wave;
     if (job >= njobs) return;
+    const gpsmi_trk_state& si = st_in[job];
+    gpsmi_trk_state& so = st_out[job];
     if (!mid[job].active) {
-        if (st_out != st_in) st_out[job] = st_in[job];
+        if (st_out != st_in) {                       // copy the closed channel's row through
+            const int* a = reinterpret_cast<const int*>(&si);
+            int* b = reinterpret_cast<int*>(&so);
+            for (int i = lane; i < (int)(sizeof(gpsmi_trk_state) / 4); i += 64) b[i] = a[i];
+        }
         return;
     }
-    gpsmi_trk_state st = st_in[job];
     gpsmi_trk_out& o = out[job];
     const int d = mid[job].delay_used;
     const int cs = P.cs, nc = P.n_cyc;
-    // S[0] = head (m < d of row 0), S[q+1] = window q, S[nc] = tail (m >= d of the last row)
-    const float2* S = partial + (size_t)job * (nc + 1);
+    const float2* S = partial + (size_t)job * (nc + 1);   // S[0] head, S[q+1] window q, S[nc] tail
+    // scalar state (same address in every lane: one broadcast load each)
+    const int nps = si.nps, df_len = si.df_len, was_locked = si.phase_locked;
+    const float freq0 = si.freq, phase0 = si.phase, omega0 = si.omega0;
+    const float prev_r = si.prev_sum_re, prev_i = si.prev_sum_im;
+    for (int i = lane; i < df_len; i += 64) s_df[wave][i] = si.df[i];
 
     // ---- prompt dumps: windows of decodeData (gpslib.py:1403-1420, :1440)
-    float gr[GPSMI_MAX_DUMPS], gi[GPSMI_MAX_DUMPS];
-    int nd = 0;
-    int n1 = st.nps + d;
-    float car_r = 0.f, car_i = 0.f;
+    const int n1 = nps + d;
+    int nd;
+    float gr = 0.f, gi = 0.f, car_r = 0.f, car_i = 0.f;
     int nps_new = 0;
-    if (n1 == 0) {                        // no carry, delay 0: the rows are the windows
-        for (int i = 0; i < nc; ++i) {
-            gr[nd] = S[i + 1].x / (float)cs;
-            gi[nd] = S[i + 1].y / (float)cs;
-            ++nd;
-        }
-        o.first_len = cs;
+    if (n1 == 0) {                       // no carry, delay 0: the rows are the windows
+        nd = nc;
+        if (lane < nd) { gr = S[lane + 1].x / (float)cs; gi = S[lane + 1].y / (float)cs; }
     } else {
-        gr[0] = (st.prev_sum_re + S[0].x) / (float)n1;
-        gi[0] = (st.prev_sum_im + S[0].y) / (float)n1;
-        nd = 1;
-        for (int j = 1; j < nc; ++j) {
-            gr[nd] = S[j].x / (float)cs;
-            gi[nd] = S[j].y / (float)cs;
-            ++nd;
+        nd = (d == 0) ? nc + 1 : nc;     // delay 0: the last code period is complete
+        if (lane == 0) {
+            gr = (prev_r + S[0].x) / (float)n1;
+            gi = (prev_i + S[0].y) / (float)n1;
+        } else if (lane < nd) {
+            gr = S[lane].x / (float)cs;
+            gi = S[lane].y / (float)cs;
         }
-        if (d == 0) {                     // the last code period is complete
-            gr[nd] = S[nc].x / (float)cs;
-            gi[nd] = S[nc].y / (float)cs;
-            ++nd;
-        } else {                          // carried into the next block
-            car_r = S[nc].x; car_i = S[nc].y;
-            nps_new = cs - d;
-        }
-        o.first_len = n1;
+        if (d != 0) { car_r = S[nc].x; car_i = S[nc].y; nps_new = cs - d; }
     }
-    o.n_dumps = nd;
-    for (int i = 0; i < GPSMI_MAX_DUMPS; ++i) {
-        o.dumps[2 * i] = i < nd ? gr[i] : 0.f;
-        o.dumps[2 * i + 1] = i < nd ? gi[i] : 0.f;
+    if (lane < GPSMI_MAX_DUMPS) {
+        o.dumps[2 * lane] = lane < nd ? gr : 0.f;
+        o.dumps[2 * lane + 1] = lane < nd ? gi : 0.f;
     }
 
     // ---- amplitude statistics (gpslib.py:1186-1187), float32 like numpy
-    float mag[GPSMI_MAX_DUMPS];
-    for (int i = 0; i < nd; ++i) mag[i] = hypotf(gr[i], gi[i]);
-    float mmean = np_sum_f32(mag, nd) / (float)nd;
-    float dev[GPSMI_MAX_DUMPS];
-    for (int i = 0; i < nd; ++i) { float e = __fsub_rn(mag[i], mmean); dev[i] = __fmul_rn(e, e); }
-    float sdev = sqrtf(np_sum_f32(dev, nd) / (float)nd);
-    o.std_dev = sdev;
-    o.amplitude = mmean / sdev;
-
-    // ---- phaseLockedLoop (gpslib.py:1215-1262)
-    float ph[GPSMI_MAX_DUMPS], real[GPSMI_MAX_DUMPS];
-    for (int i = 0; i < nd; ++i) ph[i] = atanf(gi[i] / gr[i]);
-    float dp = 0.f;
-    real[0] = ph[0];
-    for (int i = 1; i < nd; ++i) {
-        float delta = __fsub_rn(ph[i], ph[i - 1]);
-        if (fabsf(delta) > 2.0f) dp -= (delta > 0.f) ? 1.f : -1.f;
-        real[i] = __fadd_rn(ph[i], __fmul_rn(dp, kPiF));
+    const float mag = hypotf(gr, gi);
+    if (lane < nd) s_mag[wave][lane] = mag;
+    __builtin_amdgcn_wave_barrier();
+    const float mmean = np_sum_f32(s_mag[wave], nd) / (float)nd;
+    {
+        const float e = __fsub_rn(mag, mmean);
+        if (lane < nd) s_dev[wave][lane] = __fmul_rn(e, e);
     }
-    const float offset = np_sum_f32(real + (nd - 4), 4) / 4.0f;
-    const float pdev = np_sum_f32(real, nd) / (float)nd;
+    __builtin_amdgcn_wave_barrier();
+    const float sdev = sqrtf(np_sum_f32(s_dev[wave], nd) / (float)nd);
+
+    // ---- phaseLockedLoop (gpslib.py:1215-1262): unwrap by a lane prefix sum
+    const float ph = atanf(gi / gr);
+    const float ph_prev = __shfl_up(ph, 1, 64);
+    float jump = 0.f;
+    if (lane >= 1 && lane < nd) {
+        const float delta = __fsub_rn(ph, ph_prev);
+        if (fabsf(delta) > 2.0f) jump = (delta > 0.f) ? -1.f : 1.f;
+    }
+#pragma unroll
+    for (int o2 = 1; o2 < 64; o2 <<= 1) {            // inclusive scan (small integers: exact)
+        const float v = __shfl_up(jump, o2, 64);
+        if (lane >= o2) jump += v;
+    }
+    const float real = (lane == 0) ? ph : __fadd_rn(ph, __fmul_rn(jump, kPiF));
+    if (lane < nd) s_real[wave][lane] = real;
+    __builtin_amdgcn_wave_barrier();
+    const float offset = np_sum_f32(s_real[wave] + (nd - 4), 4) / 4.0f;
+    const float pdev = np_sum_f32(s_real[wave], nd) / (float)nd;
     const float max_df = 20.0f / (float)P.df_no;
-    int locked = st.phase_locked;
+    int locked = was_locked;
+    int new_len;
     float df;
     if (locked) {
-        float mean_df = np_sum_f32(st.df, st.df_len) / (float)st.df_len;
+        const float mean_df = np_sum_f32(s_df[wave], df_len) / (float)df_len;
         df = __fadd_rn(pdev, mean_df);                 // DF_GAIN2 = 1
         if (fabsf(df) > max_df) df = (df > 0.f ? 1.f : -1.f) * max_df;
-        if (st.df_len >= P.df_no) {
-            for (int i = 1; i < st.df_len; ++i) st.df[i - 1] = st.df[i];
-            st.df_len -= 1;
-        }
-        st.df[st.df_len++] = df;
+        const int shift = df_len >= P.df_no ? 1 : 0;   // drop the oldest entry
+        new_len = df_len - shift + 1;
+        for (int i = lane; i < new_len - 1; i += 64) so.df[i] = s_df[wave][i + shift];
+        if (lane == 0) so.df[new_len - 1] = df;
     } else {
         df = __fmul_rn(10.0f, pdev);                   // DF_GAIN1 = 10
-        st.df[0] = df;
-        st.df_len = 1;
+        new_len = 1;
+        if (lane == 0) so.df[0] = df;
     }
     if (fabsf(pdev) < 0.1f) locked = 1;
 
     // ---- state update (gpslib.py:1178 via :1345-1346, then :1205-1208)
-    const float om = st.omega0 != 0.f ? st.omega0 : omega_of(st.freq);
-    float phase = __fadd_rn(st.phase, __fmul_rn(om, P.t_last));
+    const float om = omega0 != 0.f ? omega0 : omega_of(freq0);
+    float phase = __fadd_rn(phase0, __fmul_rn(om, P.t_last));
     float mod = fmodf(phase, kTwoPiF);                 // np.remainder(phase, 2*pi)
     if (mod != 0.f && mod < 0.f) mod = __fadd_rn(mod, kTwoPiF);
     phase = __fadd_rn(mod, offset);
-    float freq = __fadd_rn(st.freq, df);
-    float omega0 = 0.f;                                // FREQ is float32 from here on ...
-    if (freq > P.max_freq) { freq = P.max_freq; omega0 = P.om_max; }   // ... unless clamped to
-    else if (freq < P.min_freq) { freq = P.min_freq; omega0 = P.om_min; }  // a Python float
+    float freq = __fadd_rn(freq0, df);
+    float om_new = 0.f;                                // FREQ is float32 from here on ...
+    if (freq > P.max_freq) { freq = P.max_freq; om_new = P.om_max; }   // ... unless clamped to
+    else if (freq < P.min_freq) { freq = P.min_freq; om_new = P.om_min; }  // a Python float
 
-    st.delay = d;
-    st.freq = freq;
-    st.omega0 = omega0;
-    st.phase = phase;
-    st.phase_locked = locked;
-    st.nps = nps_new;
-    st.prev_sum_re = car_r;
-    st.prev_sum_im = car_i;
-    st_out[job] = st;
-
-    o.df = df;
-    o.phase_shift = offset;
-    o.freq = freq;
-    o.phase = phase;
-    o.phase_locked = locked;
-    o.nps = nps_new;
-    o.reserved1 = 0;
+    if (lane == 0) {
+        so.prn = si.prn;
+        so.delay = d;
+        so.freq = freq;
+        so.phase = phase;
+        so.phase_locked = locked;
+        so.nps = nps_new;
+        so.prev_sum_re = car_r;
+        so.prev_sum_im = car_i;
+        so.df_len = new_len;
+        so.omega0 = om_new;
+        o.n_dumps = nd;
+        o.first_len = (n1 == 0) ? cs : n1;
+        o.std_dev = sdev;
+        o.amplitude = mmean / sdev;
+        o.df = df;
+        o.phase_shift = offset;
+        o.freq = freq;
+        o.phase = phase;
+        o.phase_locked = locked;
+        o.nps = nps_new;
+        o.reserved1 = 0;
+    }
 }
 
 }  // namespace gpsmi
@@ -285,6 +301,7 @@ struct gpsmi_trk {
     float last_total_ms = 0.f, last_corr_ms = 0.f;
     int replay_nb = 0;
     bool replay_forced = false;
+    int corr_cg = 6;
     TrkParams P;
 };
 
@@ -316,8 +333,22 @@ static int trk_launch(gpsmi_trk* h, const float2* d_iq, const gpsmi_trk_state* s
     const int nblocks = njobs / nch;
     const int ngroups = (nch + kGroupCh - 1) / kGroupCh;
     const dim3 sgrid(((nblocks + 7) / 8) * 8 * ngroups);
-    hipLaunchKernelGGL(trk_corr_kernel, sgrid, dim3(256), 0, h->stream, d_iq, st_in, forced, h->d_rep,
-                       h->d_tw, P, ngroups, nblocks, h->d_out, h->d_mid);
+    {
+        // channels per correlation workgroup: fewer channels = fewer live accumulators
+        // = more workgroups per CU for the barrier-heavy FFT phase (GPSMI_CORR_CG to tune)
+        const int cg = h->corr_cg;
+        const int ng = (nch + cg - 1) / cg;
+        const dim3 cgrid(((nblocks + 7) / 8) * 8 * ng);
+        if (cg == 6)
+            hipLaunchKernelGGL(trk_corr_kernel<6>, cgrid, dim3(256), 0, h->stream, d_iq, st_in, forced,
+                               h->d_rep, h->d_tw, P, ng, nblocks, h->d_out, h->d_mid);
+        else if (cg == 4)
+            hipLaunchKernelGGL(trk_corr_kernel<4>, cgrid, dim3(256), 0, h->stream, d_iq, st_in, forced,
+                               h->d_rep, h->d_tw, P, ng, nblocks, h->d_out, h->d_mid);
+        else
+            hipLaunchKernelGGL(trk_corr_kernel<2>, cgrid, dim3(256), 0, h->stream, d_iq, st_in, forced,
+                               h->d_rep, h->d_tw, P, ng, nblocks, h->d_out, h->d_mid);
+    }
     GPSMI_HIP(hipEventRecord(h->ev[1], h->stream));
     if (!(P.flags & 8)) {                  // default: the register-staged correlator
         const dim3 grid = sgrid, block(kStreamThreads);
@@ -354,7 +385,7 @@ static int trk_launch(gpsmi_trk* h, const float2* d_iq, const gpsmi_trk_state* s
 #undef GPSMI_LAUNCH_LDS
     }
     GPSMI_HIP(hipEventRecord(h->ev[2], h->stream));
-    hipLaunchKernelGGL(trk_epilogue_kernel, dim3((njobs + 63) / 64), dim3(64), 0, h->stream, st_in,
+    hipLaunchKernelGGL(trk_epilogue_kernel, dim3((njobs + 3) / 4), dim3(256), 0, h->stream, st_in,
                        st_out, h->d_mid, h->d_partial, P, njobs, h->d_out);
     GPSMI_HIP(hipGetLastError());
     GPSMI_HIP(hipEventRecord(h->ev[3], h->stream));
@@ -423,6 +454,8 @@ int gpsmi_trk_create(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk** out) {
     P.om_max = (float)(2.0 * M_PI * (double)cfg->max_freq);
     const char* dbg = getenv("GPSMI_DEBUG_FLAGS");
     P.flags = dbg ? atoi(dbg) : 0;
+    const char* cgs = getenv("GPSMI_CORR_CG");
+    if (cgs && (atoi(cgs) == 2 || atoi(cgs) == 4 || atoi(cgs) == 6)) h->corr_cg = atoi(cgs);
     return trk_reserve(h, max_ch);
 }
 

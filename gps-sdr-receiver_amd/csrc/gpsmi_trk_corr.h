@@ -1,6 +1,6 @@
 // Code-phase correlation of the tracking loop: cacodeCorr + findCodePhase +
 // fitCodePhase (reference src/gpslib.py:1315-1327, :1293-1304, :1268-1290) for
-// up to six channels of one block per workgroup.
+// up to CG (2, 4 or 6) channels of one block per workgroup.
 //
 // The reference wipes the carrier off the centre corr_avg code periods, sums
 // their FFTs, multiplies by conj(FFT(replica)) and takes |ifft|.  Here the sum
@@ -19,16 +19,18 @@
 
 namespace gpsmi {
 
+template <int CG>
 __global__ __launch_bounds__(256) void trk_corr_kernel(
     const float2* __restrict__ iq, const gpsmi_trk_state* __restrict__ st_in,
     const int* __restrict__ delay_forced, const float2* __restrict__ rep,
     const float2* __restrict__ tw, TrkParams P, int ngroups, int nblocks,
     gpsmi_trk_out* __restrict__ out, JobMid* __restrict__ mid) {
     __shared__ float lds[kFftLdsFloats];
+    __shared__ float lds_tw[kFftTwFloats];
     __shared__ float red[20];
-    __shared__ float2 urow[kGroupCh][32];              // U[c][i], i = row
-    __shared__ float2 step[kGroupCh];                  // exp(-j w 256/fs)
-    __shared__ StreamChan schan[kGroupCh];
+    __shared__ float2 urow[CG][32];              // U[c][i], i = row
+    __shared__ float2 step[CG];                  // exp(-j w 256/fs)
+    __shared__ StreamChan schan[CG];
 
     const int wg = blockIdx.x;
     const int xcd = wg & 7, slot = wg >> 3;
@@ -40,11 +42,12 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(
     const float2* blk = iq + (size_t)b * ((size_t)cs * P.n_cyc);
     const double inv_2pi = 0.15915494309189533576888376337251;
     const int first = (P.n_cyc - P.corr_avg) / 2;
+    const FftTw ftw = fft_setup(lds_tw, tw, t);
 
     // ---- per-channel constants (one thread each), then one barrier
-    if (t < kGroupCh * 33) {
+    if (t < CG * 33) {
         const int c = t / 33, i = t % 33;
-        const int cidx = g * kGroupCh + c;
+        const int cidx = g * CG + c;
         const int job = b * P.nch + cidx;
         StreamChan s;
         s.job = job; s.active = 0; s.om = 0.f; s.ph = 0.f; s.d = 0; s.prn = 0;
@@ -75,9 +78,9 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(
     __syncthreads();
 
     // ---- fold: acc[c][r] = sum_i U[c][i] x[i][t + 256 r]
-    v2f acc[kGroupCh][8];
+    v2f acc[CG][8];
 #pragma unroll
-    for (int c = 0; c < kGroupCh; ++c)
+    for (int c = 0; c < CG; ++c)
 #pragma unroll
         for (int r = 0; r < 8; ++r) acc[c][r] = v2f{0.f, 0.f};
     for (int i = first; i < first + P.corr_avg; ++i) {
@@ -87,13 +90,13 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(
             const float2 v = blk[(size_t)i * cs + t + 256 * r];
             x[r] = v2f{v.x, v.y};
         }
-        v2f u[kGroupCh];
+        v2f u[CG];
 #pragma unroll
-        for (int c = 0; c < kGroupCh; ++c) u[c] = v2f{urow[c][i].x, urow[c][i].y};
+        for (int c = 0; c < CG; ++c) u[c] = v2f{urow[c][i].x, urow[c][i].y};
 #pragma unroll
         for (int r = 0; r < 8; ++r)
 #pragma unroll
-            for (int c = 0; c < kGroupCh; c += 2)
+            for (int c = 0; c < CG; c += 2)
                 cmac2(acc[c][r], acc[c + 1][r], u[c], x[r], u[c + 1], x[r]);
     }
 
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(
     const float inv_fs = 1.0f / (1000.0f * (float)cs);
     const float sc = 1.0f / (float)P.corr_avg;
 #pragma unroll
-    for (int c = 0; c < kGroupCh; ++c) {
+    for (int c = 0; c < CG; ++c) {
         const StreamChan s = schan[c];
         if (!s.active) continue;                                      // uniform over the workgroup
         // V(m) for m = t + 256 r: base phasor and seven steps of 256 positions
@@ -116,16 +119,20 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(
             v[r] = cmulf(a, vm);
             vm = cmulf(vm, st256);
         }
-        __syncthreads();                       // LDS of the previous channel's FFT is free
-        fft2048(v, lds, tw, t);
+        // the replica spectrum is fetched now so that its latency hides behind the FFT
         const float2* R = rep + (size_t)s.prn * kFftN;
+        float2 rs[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) rs[q] = R[t + 256 * q];
+        __syncthreads();                       // LDS of the previous channel's FFT is free
+        fft2048(v, lds, ftw, t);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const float2 x = v[q], r = R[t + 256 * q];
+            const float2 x = v[q], r = rs[q];
             v[q] = make_float2(x.x * r.x + x.y * r.y, x.x * r.y - x.y * r.x);   // conj(x) * r
         }
         __syncthreads();
-        fft2048(v, lds, tw, t);
+        fft2048(v, lds, ftw, t);
         float mag[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q)
