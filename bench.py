@@ -52,6 +52,29 @@ SEED = 7
 N_CH = 12
 
 
+def pmc_traffic():
+    """HBM bytes per correlator launch from the committed rocprofv3 --pmc run of
+    tools/kernel_bench.py (same kernel, same batch; separate counter passes):
+    FETCH_SIZE counts KiB and on gfx950 reports half of a wide coalesced read
+    stream (MI355X_MICROARCH.md, HBM), WRITE_SIZE is exact.  None if absent."""
+    path = os.path.join(ROOT, 'profiles', 'round1', 'replay_pmc_counters.txt')
+    try:
+        fetch = write = None
+        take = False
+        for line in open(path):
+            if not line.startswith(' '):
+                take = 'trk_stream_kernel' in line
+            elif take and 'FETCH_SIZE' in line:
+                fetch = float(line.split()[1])
+            elif take and 'WRITE_SIZE' in line:
+                write = float(line.split()[1])
+        if fetch is None:
+            return None
+        return int(fetch * 1024 * 2 + (write or 0) * 1024)
+    except OSError:
+        return None
+
+
 # ---------------------------------------------------------------- input data
 def _gen_block(b):
     from gpsmi import synth
@@ -244,17 +267,21 @@ def main():
 
     corr_ms, total_ms, acq_ms = [], [], []
 
+    acq_pin = E.PinnedArray((len(f41), len(shard)), E.PEAK_DTYPE)
+
     def step(record):
+        # the search (its own handle and stream) and the tracking batch are
+        # independent: both are enqueued, then waited for once
+        acq.engine.search_async(d_iq.ptr, NGPS, shard, f41, 1, acq_pin.array,
+                                d_send.ptr if world > 1 else None)
+        trk.replay_run_async(d_iq.at(trk_base), nb)
+        trk.replay_fetch_async(pin.array)
+        acq.engine.wait()
         if world > 1:
-            acq.engine.search((d_iq.ptr, NGPS), shard, f41, 1,
-                              out_dev=d_send.ptr)
             E.check(lib.gpsmi_comm_allgather_peaks(
                 comm, d_send.ptr, d_recv.ptr, len(f41) * len(shard),
                 E.ptr(gathered)), 'allgather')
-        else:
-            acq.engine.search((d_iq.ptr, NGPS), shard, f41, 1)
-        trk.replay_run(d_iq.at(trk_base), nb)
-        trk.replay_fetch(pin.array)
+        trk.wait()
         if record:
             t, c = trk.last_ms()
             total_ms.append(t)
@@ -314,7 +341,8 @@ def main():
                 'bound': 'hbm', 'kernel': 'trk_stream_kernel',
                 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                'traffic': None, 'kernel_ms': round(k_ms, 4),
+                'traffic': pmc_traffic() if nb == 1024 else None,
+                'kernel_ms': round(k_ms, 4),
                 'algorithmic_bytes_per_launch': alg_bytes,
             },
             'kernels_ms': {
@@ -344,6 +372,7 @@ def main():
         if not (same and chained):
             sys.exit('bench: replay does not reproduce the closed loop')
     pin.free()
+    acq_pin.free()
     if comm is not None:
         lib.gpsmi_comm_destroy(comm)
     if dist is not None:

@@ -172,7 +172,10 @@ struct gpsmi_acq {
     size_t cell_cap = 0;
     float2* d_nbr = nullptr;
     float last_ms = 0.f;
+    bool pending = false;
 };
+
+extern "C" int gpsmi_acq_wait(gpsmi_acq* h);
 
 static int acq_reserve(gpsmi_acq* h, int nbins, int nsv) {
     if ((size_t)nbins > h->spec_cap) {
@@ -254,7 +257,7 @@ int gpsmi_acq_set_replica(gpsmi_acq* h, int prn, const float* spectrum) {
 
 static int acq_search_impl(gpsmi_acq* h, const void* d_iq, size_t n, const int32_t* prn, int nsv,
                            const double* freqs, int nbins, int n_avg, gpsmi_peak* out,
-                           void* out_dev, float* nbr) {
+                           void* out_dev, float* nbr, bool wait = true) {
     GPSMI_REQUIRE(h && d_iq && prn && freqs, "null argument");
     GPSMI_REQUIRE(out || out_dev, "no output requested");
     GPSMI_REQUIRE(nsv >= 0 && nsv <= GPSMI_MAX_PRN, "nsv out of range");
@@ -271,11 +274,13 @@ static int acq_search_impl(gpsmi_acq* h, const void* d_iq, size_t n, const int32
     GPSMI_HIP(hipSetDevice(h->cfg.device));
     int rc = acq_reserve(h, nbins, nsv);
     if (rc) return rc;
+    // small parameter uploads are blocking copies: the caller's arrays (and the
+    // temporary below) are consumed before this function returns
     std::vector<float> om(nbins);
     for (int b = 0; b < nbins; ++b) om[b] = (float)(2.0 * M_PI * freqs[b]);
-    GPSMI_HIP(hipMemcpyAsync(h->d_omega, om.data(), nbins * sizeof(float), hipMemcpyHostToDevice,
-                             h->stream));
-    GPSMI_HIP(hipMemcpyAsync(h->d_slot, prn, nsv * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    GPSMI_HIP(hipStreamSynchronize(h->stream));
+    GPSMI_HIP(hipMemcpy(h->d_omega, om.data(), nbins * sizeof(float), hipMemcpyHostToDevice));
+    GPSMI_HIP(hipMemcpy(h->d_slot, prn, nsv * sizeof(int), hipMemcpyHostToDevice));
     GPSMI_HIP(hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(acq_spectrum_kernel, dim3(nbins), dim3(256), 0, h->stream,
                        (const float2*)d_iq, h->d_t32, h->d_omega, n_avg, h->d_spec, h->d_tw);
@@ -291,9 +296,25 @@ static int acq_search_impl(gpsmi_acq* h, const void* d_iq, size_t n, const int32
     if (nbr)
         GPSMI_HIP(hipMemcpyAsync(nbr, h->d_nbr, (size_t)nbins * nsv * sizeof(float2),
                                  hipMemcpyDeviceToHost, h->stream));
+    h->pending = true;
+    if (!wait) return GPSMI_OK;
+    return gpsmi_acq_wait(h);
+}
+
+int gpsmi_acq_wait(gpsmi_acq* h) {
+    GPSMI_REQUIRE(h, "null handle");
+    if (!h->pending) return GPSMI_OK;
+    GPSMI_HIP(hipSetDevice(h->cfg.device));
     GPSMI_HIP(hipStreamSynchronize(h->stream));
     GPSMI_HIP(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+    h->pending = false;
     return GPSMI_OK;
+}
+
+int gpsmi_acq_search_dev_async(gpsmi_acq* h, const void* d_iq, size_t n, const int32_t* prn,
+                               int nsv, const double* freqs, int nbins, int n_avg,
+                               gpsmi_peak* out, void* out_dev) {
+    return acq_search_impl(h, d_iq, n, prn, nsv, freqs, nbins, n_avg, out, out_dev, nullptr, false);
 }
 
 int gpsmi_acq_search_dev(gpsmi_acq* h, const void* d_iq, size_t n, const int32_t* prn, int nsv,

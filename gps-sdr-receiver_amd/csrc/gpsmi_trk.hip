@@ -301,6 +301,7 @@ struct gpsmi_trk {
     float last_total_ms = 0.f, last_corr_ms = 0.f;
     int replay_nb = 0;
     bool replay_forced = false;
+    bool timing_pending = false;
     int corr_cg = 6;
     TrkParams P;
 };
@@ -610,30 +611,49 @@ int gpsmi_trk_replay_load(gpsmi_trk* h, int nb, const gpsmi_trk_state* table,
     return GPSMI_OK;
 }
 
-int gpsmi_trk_replay_run(gpsmi_trk* h, const void* d_iq, int nb) {
+int gpsmi_trk_replay_run_async(gpsmi_trk* h, const void* d_iq, int nb) {
     GPSMI_REQUIRE(h && d_iq, "null argument");
     if (nb != h->replay_nb || nb < 1)
         return fail(GPSMI_E_STATE, "replay_run(nb=%d) without a matching replay_load (nb=%d)", nb,
                     h->replay_nb);
     GPSMI_HIP(hipSetDevice(h->cfg.device));
     const int nch = h->max_ch;
-    int rc = trk_launch(h, (const float2*)d_iq, h->d_tab_in, h->d_tab_out,
-                        h->replay_forced ? h->d_forced : nullptr, nb * nch, nch);
-    if (rc) return rc;
+    h->timing_pending = true;
+    return trk_launch(h, (const float2*)d_iq, h->d_tab_in, h->d_tab_out,
+                      h->replay_forced ? h->d_forced : nullptr, nb * nch, nch);
+}
+
+int gpsmi_trk_wait(gpsmi_trk* h) {
+    GPSMI_REQUIRE(h, "null handle");
+    GPSMI_HIP(hipSetDevice(h->cfg.device));
     GPSMI_HIP(hipStreamSynchronize(h->stream));
-    GPSMI_HIP(hipEventElapsedTime(&h->last_total_ms, h->ev[0], h->ev[3]));
-    GPSMI_HIP(hipEventElapsedTime(&h->last_corr_ms, h->ev[1], h->ev[2]));
+    if (h->timing_pending) {
+        GPSMI_HIP(hipEventElapsedTime(&h->last_total_ms, h->ev[0], h->ev[3]));
+        GPSMI_HIP(hipEventElapsedTime(&h->last_corr_ms, h->ev[1], h->ev[2]));
+        h->timing_pending = false;
+    }
     return GPSMI_OK;
 }
 
-int gpsmi_trk_replay_fetch(gpsmi_trk* h, gpsmi_trk_out* out, size_t n) {
+int gpsmi_trk_replay_run(gpsmi_trk* h, const void* d_iq, int nb) {
+    int rc = gpsmi_trk_replay_run_async(h, d_iq, nb);
+    if (rc) return rc;
+    return gpsmi_trk_wait(h);
+}
+
+int gpsmi_trk_replay_fetch_async(gpsmi_trk* h, gpsmi_trk_out* out, size_t n) {
     GPSMI_REQUIRE(h && out, "null argument");
     GPSMI_REQUIRE(n <= (size_t)h->replay_nb * h->max_ch, "more records than the last replay ran");
     GPSMI_HIP(hipSetDevice(h->cfg.device));
     GPSMI_HIP(hipMemcpyAsync(out, h->d_out, n * sizeof(gpsmi_trk_out), hipMemcpyDeviceToHost,
                              h->stream));
-    GPSMI_HIP(hipStreamSynchronize(h->stream));
     return GPSMI_OK;
+}
+
+int gpsmi_trk_replay_fetch(gpsmi_trk* h, gpsmi_trk_out* out, size_t n) {
+    int rc = gpsmi_trk_replay_fetch_async(h, out, n);
+    if (rc) return rc;
+    return gpsmi_trk_wait(h);
 }
 
 int gpsmi_trk_replay(gpsmi_trk* h, const void* d_iq, int nb, const gpsmi_trk_state* table,

@@ -60,12 +60,14 @@ EXPORTS = [
     'gpsmi_dev_unpack_u8iq',
     'gpsmi_acq_create', 'gpsmi_acq_destroy', 'gpsmi_acq_set_replica',
     'gpsmi_acq_search', 'gpsmi_acq_search_dev', 'gpsmi_acq_search_ex',
+    'gpsmi_acq_search_dev_async', 'gpsmi_acq_wait',
     'gpsmi_acq_last_ms',
     'gpsmi_trk_create', 'gpsmi_trk_destroy', 'gpsmi_trk_set_replica',
     'gpsmi_trk_open', 'gpsmi_trk_close', 'gpsmi_trk_get_state',
     'gpsmi_trk_set_state', 'gpsmi_trk_erase_prev', 'gpsmi_trk_process',
     'gpsmi_trk_process_dev', 'gpsmi_trk_replay', 'gpsmi_trk_replay_load',
     'gpsmi_trk_replay_run', 'gpsmi_trk_replay_fetch', 'gpsmi_trk_replay_states',
+    'gpsmi_trk_replay_run_async', 'gpsmi_trk_replay_fetch_async', 'gpsmi_trk_wait',
     'gpsmi_trk_last_ms',
     'gpsmi_comm_unique_id', 'gpsmi_comm_create', 'gpsmi_comm_destroy',
     'gpsmi_comm_allgather_peaks',
@@ -110,6 +112,9 @@ def load():
                                  vp, vp],
         'gpsmi_acq_search_ex': [vp, vp, sz, vp, C.c_int, vp, C.c_int, C.c_int, vp,
                                 vp],
+        'gpsmi_acq_search_dev_async': [vp, vp, sz, vp, C.c_int, vp, C.c_int, C.c_int,
+                                       vp, vp],
+        'gpsmi_acq_wait': [vp],
         'gpsmi_acq_last_ms': [vp, P(f32)],
         'gpsmi_trk_create': [P(Cfg), C.c_int, P(vp)],
         'gpsmi_trk_destroy': [vp],
@@ -126,6 +131,9 @@ def load():
         'gpsmi_trk_replay_load': [vp, C.c_int, vp, vp],
         'gpsmi_trk_replay_run': [vp, vp, C.c_int],
         'gpsmi_trk_replay_fetch': [vp, vp, sz],
+        'gpsmi_trk_replay_run_async': [vp, vp, C.c_int],
+        'gpsmi_trk_replay_fetch_async': [vp, vp, sz],
+        'gpsmi_trk_wait': [vp],
         'gpsmi_host_alloc': [sz, P(vp)],
         'gpsmi_host_free': [vp],
         'gpsmi_trk_last_ms': [vp, P(f32), P(f32)],

@@ -169,6 +169,18 @@ class AcqEngine:
                 len(f_a), n_avg, ptr(out)), 'gpsmi_acq_search')
         return out
 
+    def search_async(self, d_iq, n, prns, freqs, n_avg, out, out_dev=None):
+        """Enqueue a search on device-resident iq; `out` is a pinned PEAK_DTYPE
+        array [nbins, nsv] filled when wait() returns."""
+        prn_a = np.ascontiguousarray(prns, dtype=np.int32)
+        f_a = np.ascontiguousarray(freqs, dtype=np.float64)
+        check(self.lib.gpsmi_acq_search_dev_async(
+            self.h, d_iq, n, ptr(prn_a), len(prn_a), ptr(f_a), len(f_a), n_avg,
+            ptr(out), out_dev), 'gpsmi_acq_search_dev_async')
+
+    def wait(self):
+        check(self.lib.gpsmi_acq_wait(self.h), 'gpsmi_acq_wait')
+
     def search_ex(self, iq, prns, freqs, n_avg):
         """search() plus corr[argmax-1], corr[argmax+1] per cell: (table, nbr)."""
         prn_a = np.ascontiguousarray(prns, dtype=np.int32)
@@ -284,6 +296,17 @@ class TrkEngine:
     def replay_run(self, d_iq, nb):
         check(self.lib.gpsmi_trk_replay_run(self.h, d_iq, nb),
               'gpsmi_trk_replay_run')
+
+    def replay_run_async(self, d_iq, nb):
+        check(self.lib.gpsmi_trk_replay_run_async(self.h, d_iq, nb),
+              'gpsmi_trk_replay_run_async')
+
+    def replay_fetch_async(self, out):
+        check(self.lib.gpsmi_trk_replay_fetch_async(self.h, ptr(out), out.size),
+              'gpsmi_trk_replay_fetch_async')
+
+    def wait(self):
+        check(self.lib.gpsmi_trk_wait(self.h), 'gpsmi_trk_wait')
 
     def replay_fetch(self, out):
         """out: C-contiguous OUT_DTYPE array (ideally from pinned_array)."""

@@ -122,6 +122,15 @@ int gpsmi_acq_search_ex(gpsmi_acq* h, const float* iq, size_t n,
                         const int32_t* prn, int nsv,
                         const double* freqs_hz, int nbins, int n_avg,
                         gpsmi_peak* out, float* nbr);
+/* Non-blocking form for pipelines: enqueues the search (and the copies into
+ * out / out_dev) on the handle's stream and returns; out must be page-locked
+ * (gpsmi_host_alloc) and stay valid until gpsmi_acq_wait(), which blocks until
+ * the work is done.  prn / freqs are consumed before the call returns.         */
+int gpsmi_acq_search_dev_async(gpsmi_acq* h, const void* d_iq, size_t n,
+                               const int32_t* prn, int nsv,
+                               const double* freqs_hz, int nbins, int n_avg,
+                               gpsmi_peak* out, void* out_dev);
+int gpsmi_acq_wait(gpsmi_acq* h);
 /* Timing of the last search on the handle's stream (HIP events), ms.          */
 int gpsmi_acq_last_ms(gpsmi_acq* h, float* ms);
 
@@ -223,6 +232,11 @@ int gpsmi_trk_replay_load(gpsmi_trk* h, int nb, const gpsmi_trk_state* table,
                           const int32_t* delay_used);
 int gpsmi_trk_replay_run(gpsmi_trk* h, const void* d_iq, int nb);
 int gpsmi_trk_replay_fetch(gpsmi_trk* h, gpsmi_trk_out* out, size_t n);
+/* Non-blocking run / fetch on the handle's stream and the matching wait; out
+ * must be page-locked and stay valid until gpsmi_trk_wait().                  */
+int gpsmi_trk_replay_run_async(gpsmi_trk* h, const void* d_iq, int nb);
+int gpsmi_trk_replay_fetch_async(gpsmi_trk* h, gpsmi_trk_out* out, size_t n);
+int gpsmi_trk_wait(gpsmi_trk* h);
 /* State at the END of every job of the last replay, [nb][nch]: equals the next
  * row of the table when the table is a closed-loop trajectory.               */
 int gpsmi_trk_replay_states(gpsmi_trk* h, gpsmi_trk_state* states, size_t n);
