@@ -18,6 +18,7 @@ fitCodePhase, decodeData's sums, the statistics and the PLL.
 """
 import numpy as np
 
+from . import navbits
 from .acquisition import norm_max_corr
 from .engine import AcqEngine, Config, TrkEngine, dumps_of
 
@@ -146,8 +147,8 @@ class HostChannel:
             bits, stamps = self.logicalBits()
             self.GPSBITS = np.append(self.GPSBITS, bits)
             self.GPSBITS_ST = np.append(self.GPSBITS_ST, stamps)
-            # subframe extraction (evalGpsBits / Subframe, gpslib.py:1504-1580,
-            # :96-419) is the next scope row: bits accumulate
+            frames, self.GPSBITS, self.GPSBITS_ST = navbits.eval_gps_bits(
+                self.GPSBITS, self.GPSBITS_ST)              # gpslib.py:1504-1580
         return frames
 
     # ---- the tracking branch of process() after the GPU work (gpslib.py:1178-1208)

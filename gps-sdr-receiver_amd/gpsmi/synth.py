@@ -63,6 +63,7 @@ class Sat:
     delay_rate: float = None  # samples per sample; None -> -doppler/1575.42e6
     data_bits: bool = True
     doppler_rate: float = 0.0  # Hz/s
+    nav_bits: object = None   # optional 0/1 array: the 50 bit/s message, repeated
 
 
 @dataclass
@@ -104,7 +105,11 @@ class Scene:
             a = off - j
             rep = self._replica(s.prn)
             code = (1.0 - a) * rep[j % cs] + a * rep[(j + 1) % cs]
-            if s.data_bits:
+            if s.nav_bits is not None:
+                bit_no = np.floor(period / 20.0).astype(np.int64)
+                nav = np.asarray(s.nav_bits)
+                code = code * (2.0 * nav[bit_no % len(nav)] - 1.0)
+            elif s.data_bits:
                 bit_no = np.floor(period / 20.0).astype(np.int64)
                 h = _mix64((bit_no + (1 << 40)).astype(np.uint64)
                            ^ np.uint64(self.seed * 1000 + s.prn))

@@ -205,6 +205,141 @@ def get_new_sats(act, found, cpq, max_sat):
 
 
 # --------------------------------------------------------------------------
+# navigation bits: subframe check / extraction (gpslib.py:96-419)
+# --------------------------------------------------------------------------
+GPS_PI = 3.1415926535898                  # gpslib.py:16
+PREAMBLE = np.array([1, 0, 0, 0, 1, 0, 1, 1], dtype=np.int8)      # gpslib.py:109
+
+
+def bin_to_int(bits, signed=False):
+    """BinToInt (gpslib.py:408-419)."""
+    neg = signed and bits[0] == 1
+    if neg:
+        bits = 1 - bits
+    z, f = 0, 1
+    for b in reversed(bits):
+        z += int(b) * f
+        f *= 2
+    return -(z + 1) if neg else z
+
+
+def check_parity(words):
+    """CheckParity (gpslib.py:379-405): index of the first failing word (1..9)
+    or 0.  Words whose predecessor ends in D30* = 1 are complemented in place;
+    word 0 is never checked."""
+    taps = ((28, (0, 1, 2, 4, 5, 9, 10, 11, 12, 13, 16, 17, 19, 22)),
+            (29, (1, 2, 3, 5, 6, 10, 11, 12, 13, 14, 17, 18, 20, 23)),
+            (28, (0, 2, 3, 4, 6, 7, 11, 12, 13, 14, 15, 18, 19, 21)),
+            (29, (1, 3, 4, 5, 7, 8, 12, 13, 14, 15, 16, 19, 20, 22)),
+            (29, (0, 2, 4, 5, 6, 8, 9, 13, 14, 15, 16, 17, 20, 21, 23)),
+            (28, (2, 4, 5, 7, 8, 9, 10, 12, 14, 18, 21, 22, 23)))
+    for i in range(1, 10):
+        if words[i - 1, 29] == 1:
+            words[i, :24] = 1 - words[i, :24]
+        d = words[i, :24]
+        for k, (prev, idx) in enumerate(taps):
+            bit = int(words[i - 1, prev])
+            for j in idx:
+                bit ^= int(d[j])
+            if bit != words[i, 24 + k]:
+                return i
+    return 0
+
+
+def extract_subframe(bits):
+    """Subframe.Extract with getDataSub1..3 (gpslib.py:282-371) ->
+    (status, dict); status codes as gpslib.py:97-108."""
+    if len(bits) != 300:
+        return 1, {}
+    data = np.copy(bits)
+    if not (data[:8] == PREAMBLE).all():
+        data = 1 - data
+        if not (data[:8] == PREAMBLE).all():
+            return 2, {}
+    w = np.reshape(data, (10, 30))
+    if check_parity(w) > 0:
+        return 3, {}
+    f = {'tow': bin_to_int(w[1, :17]), 'ID': bin_to_int(w[1, 19:22])}
+    if f['ID'] < 1 or f['ID'] > 5:
+        return 4, {}
+    cat = np.append
+    if f['ID'] == 1:
+        f['weekNum'] = bin_to_int(w[2, :10])
+        f['satAcc'] = bin_to_int(w[2, 12:16])
+        f['satHealth'] = bin_to_int(w[2, 16:22])
+        f['IODC'] = bin_to_int(cat(w[2, 22:24], w[7, :8]))
+        f['Tgd'] = bin_to_int(w[6, 16:24], True) * 2 ** (-31)
+        f['Toc'] = bin_to_int(w[7, 8:24]) * 16
+        f['af2'] = bin_to_int(w[8, 0:8], True) * 2.0 ** (-55)
+        f['af1'] = bin_to_int(w[8, 8:24], True) * 2.0 ** (-43)
+        f['af0'] = bin_to_int(w[9, 0:22], True) * 2.0 ** (-31)
+    elif f['ID'] == 2:
+        f['IODE2'] = bin_to_int(w[2, 0:8])
+        f['Crs'] = bin_to_int(w[2, 8:24], True) * 2.0 ** (-5)
+        f['deltaN'] = bin_to_int(w[3, 0:16], True) * 2.0 ** (-43) * GPS_PI
+        f['M0'] = bin_to_int(cat(w[3, 16:24], w[4, 0:24]), True) * 2.0 ** (-31) * GPS_PI
+        f['Cuc'] = bin_to_int(w[5, 0:16], True) * 2.0 ** (-29)
+        f['e'] = bin_to_int(cat(w[5, 16:24], w[6, 0:24])) * 2 ** (-33)
+        f['Cus'] = bin_to_int(w[7, 0:16], True) * 2.0 ** (-29)
+        f['sqrtA'] = bin_to_int(cat(w[7, 16:24], w[8, 0:24])) * 2.0 ** (-19)
+        f['Toe'] = bin_to_int(w[9, 0:16]) * 16
+    elif f['ID'] == 3:
+        f['Cic'] = bin_to_int(w[2, 0:16], True) * 2.0 ** (-29)
+        f['omegaBig'] = bin_to_int(cat(w[2, 16:24], w[3, 0:24]), True) * 2.0 ** (-31) * GPS_PI
+        f['Cis'] = bin_to_int(w[4, 0:16], True) * 2.0 ** (-29)
+        f['i0'] = bin_to_int(cat(w[4, 16:24], w[5, 0:24]), True) * 2.0 ** (-31) * GPS_PI
+        f['Crc'] = bin_to_int(w[6, 0:16], True) * 2.0 ** (-5)
+        f['omegaSmall'] = bin_to_int(cat(w[6, 16:24], w[7, 0:24]), True) * 2.0 ** (-31) * GPS_PI
+        f['omegaDot'] = bin_to_int(w[8, 0:24], True) * 2.0 ** (-43) * GPS_PI
+        f['IDOT'] = bin_to_int(w[9, 8:22], True) * 2.0 ** (-43) * GPS_PI
+        f['IODE3'] = bin_to_int(w[9, 0:8])
+    return 0, f
+
+
+_FRAME_KEYS = {
+    1: ('ID', 'tow', 'weekNum', 'satAcc', 'satHealth', 'Tgd', 'IODC', 'Toc', 'af2', 'af1',
+        'af0'),
+    2: ('ID', 'tow', 'Crs', 'deltaN', 'M0', 'Cuc', 'IODE2', 'e', 'Cus', 'sqrtA', 'Toe'),
+    3: ('ID', 'tow', 'Cic', 'omegaBig', 'Cis', 'i0', 'IODE3', 'Crc', 'omegaSmall',
+        'omegaDot', 'IDOT'),
+    4: ('ID', 'tow'), 5: ('ID', 'tow'),
+}
+
+
+def eval_gps_bits(gps_bits, stamps):
+    """evalGpsBits (gpslib.py:1504-1580)."""
+    result = []
+    if len(gps_bits) < 300:
+        return result, gps_bits, stamps
+    gb = np.copy(gps_bits)
+    pre = np.array([1, -1, -1, -1, 1, -1, 1, 1], dtype=np.int8)       # gpslib.py:1045
+    corr = np.correlate(gb, pre, mode='same')
+    loc = [i - 4 for i in range(len(corr)) if abs(corr[i]) == 8]
+    start = 0
+    if len(loc) > 0:
+        gb[gb == -1] = 0
+        lp = 0
+        start = loc[lp]
+        ok = True
+        while ok and start + 300 < len(gb):
+            status, f = extract_subframe(gb[start:start + 300])
+            if status == 0:
+                res = {k: f[k] for k in _FRAME_KEYS[f['ID']]}
+                res['ST'] = stamps[start]
+                result.append(res)
+                start += 300
+            else:
+                ok = False
+                while not ok and lp < len(loc) - 1:
+                    lp += 1
+                    s = loc[lp]
+                    ok = s > start
+                if ok:
+                    start = s
+    return result, gps_bits[start:], stamps[start:]
+
+
+# --------------------------------------------------------------------------
 # tracking (gpslib.py:1044-1446, signal part)
 # --------------------------------------------------------------------------
 def fit_code_phase(corr, mx):
@@ -221,8 +356,8 @@ def fit_code_phase(corr, mx):
 
 class SatStream:
     """Numeric and control restatement of gpslib.SatStream (gpslib.py:1044-1446)
-    including the edge list and its slicing into 20-ms bits; subframe
-    extraction (evalGpsBits/Subframe) is host logic of the 'next' scope."""
+    including the edge list, its slicing into 20-ms bits and subframe
+    extraction (evalGpsBits / Subframe)."""
     DF_GAIN1 = 10                        # gpslib.py:1046
     DF_GAIN2 = 1                         # gpslib.py:1047
     MIN_CORR_Q = -0.9                    # gpslib.py:1048
@@ -409,12 +544,7 @@ class SatStream:
         return frames
 
     def eval_gps_bits(self, bits, stamps):
-        """evalGpsBits (gpslib.py:1504-1580).  Subframe extraction belongs to
-        the 'next' scope; below 300 bits the reference
-        returns its inputs untouched, which is all the fixtures exercise."""
-        if len(bits) < 300:
-            return [], bits, stamps
-        raise NotImplementedError('subframe extraction: SURVEY.md 8(f) n1')
+        return eval_gps_bits(bits, stamps)
 
     # -- PLL (gpslib.py:1215-1262)
     def phase_locked_loop(self, dumps):

@@ -13,6 +13,7 @@ detected.
     python oracle/make_golden.py            # all fixtures (two sub-processes)
     python oracle/make_golden.py default    # CODE_SAMPLES=2048,  N_CYC=32
     python oracle/make_golden.py hirate     # CODE_SAMPLES=16368, N_CYC=8
+    python oracle/make_golden.py navbits    # Subframe / evalGpsBits on constructed frames
 
 The reference binds its configuration at import time (``from gpsglob import``),
 so each configuration runs in its own interpreter.
@@ -198,10 +199,89 @@ def run(config):
           f'{len(found)} SVs found')
 
 
+def run_navbits():
+    """Subframe.Extract and SatStream.evalGpsBits of the reference on
+    constructed 300-bit frames (gpsmi.navbits.encode_subframe builds valid
+    IS-GPS-200 parity; the reference has no encoder) -> ref_navbits.npz."""
+    import json
+    import numpy as np
+    gpsglob, gpslib, gpsrecv = _import_reference(2048, 32)
+    from gpsmi import navbits as nb
+    rng = np.random.default_rng(20240)
+    frames, status, fields = [], [], []
+    ds29 = ds30 = 0
+    chain = []
+    for k in range(60):
+        w = rng.integers(0, 2, (10, 24)).astype(np.int8)
+        w[0, :8] = nb.PREAMBLE_BITS
+        sid = (k % 5) + 1
+        kind = 'ok'
+        if k % 12 == 7:
+            sid, kind = (0, 6, 7)[(k // 12) % 3], 'bad_id'
+        w[1, 19:22] = [(sid >> 2) & 1, (sid >> 1) & 1, sid & 1]
+        f = nb.encode_subframe(w, ds29, ds30)
+        ds29, ds30 = int(f[298]), int(f[299])
+        chain.append(f.copy())
+        if k % 12 == 3:
+            f = 1 - f; kind = 'inverted'
+        elif k % 12 == 5:
+            f[30 * (1 + k % 9) + k % 24] ^= 1; kind = 'parity'
+        elif k % 12 == 9:
+            f[3] ^= 1; kind = 'preamble'
+        elif k % 12 == 11:
+            f = f[:299]; kind = 'short'
+        sf = gpslib.Subframe()
+        st = sf.Extract(f)
+        d = {}
+        if st == 0:
+            d = {'ID': sf.ID, 'tow': sf.tow}
+            for name in ('weekNum satAcc satHealth Tgd IODC Toc af2 af1 af0 '
+                         'Crs deltaN M0 Cuc IODE2 e Cus sqrtA Toe '
+                         'Cic omegaBig Cis i0 IODE3 Crc omegaSmall omegaDot IDOT').split():
+                v = getattr(sf, name)
+                if {1: 'weekNum satAcc satHealth Tgd IODC Toc af2 af1 af0',
+                    2: 'Crs deltaN M0 Cuc IODE2 e Cus sqrtA Toe',
+                    3: 'Cic omegaBig Cis i0 IODE3 Crc omegaSmall omegaDot IDOT'}.get(
+                        sf.ID, '').split().count(name):
+                    d[name] = v
+        pad = np.zeros(300, np.int8)
+        pad[:len(f)] = f
+        frames.append(pad)
+        status.append((st, len(f)))
+        fields.append(d)
+    # streams through evalGpsBits: noise + a run of consecutive valid frames + noise,
+    # normal and inverted polarity, and one with a corrupted frame in the middle
+    streams = []
+    ss = gpslib.SatStream(5, 0.0)
+    for variant in range(3):
+        run = [c.copy() for c in chain[10 * variant:10 * variant + 6]]
+        if variant == 2:
+            run[2][77] ^= 1
+        bits01 = np.concatenate([rng.integers(0, 2, 41 + 13 * variant).astype(np.int8)]
+                                + run + [rng.integers(0, 2, 120).astype(np.int8)])
+        pm = (2 * bits01 - 1).astype(np.int8)
+        if variant == 1:
+            pm = (-pm).astype(np.int8)
+        stamps = (np.arange(len(pm), dtype=np.int64) * 40960 + 777)
+        res, rest, rest_st = ss.evalGpsBits(pm, stamps)
+        streams.append(dict(bits=pm.tolist(), stamps=stamps.tolist(),
+                            frames=[{k: (int(v) if isinstance(v, (int, np.integer))
+                                         else float(v)) for k, v in r.items()} for r in res],
+                            keys=[list(r.keys()) for r in res],
+                            rest=len(rest), rest_first_stamp=int(rest_st[0])))
+    path = os.path.join(GOLD, 'ref_navbits.npz')
+    np.savez_compressed(path, frames=np.array(frames), status=np.array(status),
+                        fields=np.array(json.dumps(fields)),
+                        streams=np.array(json.dumps(streams)))
+    print(path, os.path.getsize(path), 'bytes;', sum(1 for s, _ in status if s == 0),
+          'valid frames;', [len(s['frames']) for s in streams], 'frames per stream')
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1:
-        run(sys.argv[1])
+        run_navbits() if sys.argv[1] == 'navbits' else run(sys.argv[1])
     else:
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), 'navbits'])
         for cfg in ('default', 'hirate'):
             subprocess.check_call([sys.executable, os.path.abspath(__file__),
                                    cfg])
