@@ -1,0 +1,99 @@
+"""GPU: the block loop + hand-off (gpsmi.pipeline.Receiver, mirror of
+gpsrecv.processData's data path, reference gpsrecv.py:445-548) against the same
+loop written with the oracle's functions: same datagrams at the same blocks,
+same structure after unpickling, numbers within the tracking tolerances."""
+import pickle
+
+import numpy as np
+import pytest
+
+import gps_oracle as orc
+from conftest import scene_blocks
+
+pytestmark = pytest.mark.gpu
+N_BLOCKS = 45
+
+
+def oracle_process_data(blocks):
+    """processData's data path (gpsrecv.py:466-519) with oracle pieces."""
+    p = orc.Params()
+    t = orc.sec_time(p)
+    spectra = {s: orc.fft_cacode(s) for s in range(2, 33)}
+    sat_lst, found, freq = list(range(2, 33)), [], p.min_freq
+    sweeping, smp_time = True, np.int64(0)
+    streams, act = {}, set()
+    co_ph_lst, cp_q_lst, skipped, out = {}, {}, 0, []
+    for i, data in enumerate(blocks):
+        smp_time += p.ngps
+        if sweeping:
+            ready, freq, found = orc.sweep_all_sats(data, freq, sat_lst, found,
+                                                    p.it_sweep_all, p, spectra, t)
+            if ready:
+                sweeping = False
+                dele, new = orc.get_new_sats(act, found, cp_q_lst, p.max_sat)
+                for s in new:
+                    _, _, f0, d0 = [e for e in found if e[1] == s][0]
+                    streams[s] = orc.SatStream(s, f0, p, delay=d0)
+                    act.add(s)
+            continue
+        frame_lst = []
+        stream_no = smp_time // p.ngps
+        for s in act:
+            sw, f_lst, co_ph, cp_q = streams[s].process(data, smp_time)
+            frame_lst += f_lst
+            cp_q_lst[s] = cp_q
+            if co_ph >= 0:
+                co_ph_lst.setdefault(s, []).append((stream_no, co_ph))
+        if frame_lst:
+            out.append((i, (skipped, frame_lst, co_ph_lst)))
+            co_ph_lst, skipped = {}, 0
+    return out
+
+
+def test_block_loop_and_hand_off():
+    from gpsmi.pipeline import Receiver
+    blocks = scene_blocks('default', 0, N_BLOCKS)
+    ref = oracle_process_data(blocks)
+    rx = Receiver()
+    got = []
+    for i, b in enumerate(blocks):
+        res = rx.feed(b)
+        if res is not None:
+            got.append((i, pickle.loads(res)))
+    assert len(rx.act_sat_set) == 11                       # MAX_SAT of 12 acquired
+    assert [i for i, _ in got] == [i for i, _ in ref] and len(got) >= 1
+    for (_, (sk_a, fr_a, cp_a)), (_, (sk_b, fr_b, cp_b)) in zip(got, ref):
+        assert sk_a == sk_b == 0
+        assert [f['SAT'] for f in fr_a] == [f['SAT'] for f in fr_b]
+        for fa, fb in zip(fr_a, fr_b):
+            assert list(fa.keys()) == list(fb.keys())
+            assert fa['SWP'] == fb['SWP']
+            assert abs(float(fa['FRQ']) - float(fb['FRQ'])) < 0.05
+            assert abs(float(fa['AMP']) - float(fb['AMP'])) < 2e-2
+            assert abs(float(fa['CRM']) - float(fb['CRM'])) < 2e-2
+        assert sorted(cp_a) == sorted(cp_b)
+        for s in cp_a:
+            assert [n for n, _ in cp_a[s]] == [n for n, _ in cp_b[s]]
+            np.testing.assert_allclose([c for _, c in cp_a[s]], [c for _, c in cp_b[s]],
+                                       atol=2e-3)
+    # a SWEEP command restarts the cold search, STOP ends the run
+    rx.command(b'SWEEP')
+    assert rx.sweep_all_freq and rx.sat_lst == list(range(2, 33)) and rx.found_sats == []
+    assert rx.feed(blocks[0]) is None
+    rx.command(b'STOP')
+    assert rx.running is False
+    rx.close()
+
+
+def test_skipped_streams_are_reported():
+    from gpsmi.pipeline import Receiver
+    blocks = scene_blocks('default', 0, 40)
+    rx = Receiver()
+    out = None
+    for i, b in enumerate(blocks):
+        res = rx.feed(b, skip=2 if i == 20 else 0)         # ring buffer lost two streams
+        out = res or out
+    skipped, frames, co_ph = pickle.loads(out)
+    assert skipped == 2 * 65536
+    assert int(rx.smp_time) == (40 + 2) * 65536
+    rx.close()
