@@ -158,6 +158,8 @@ def main():
     ap.add_argument('--blocks', type=int, default=1024)
     ap.add_argument('--cpu-blocks', type=int, default=192)
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--rehearse', action='store_true',
+                    help='N > 1 on a box with fewer GPUs: ranks share devices, RCCL skipped')
     a = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -191,6 +193,8 @@ def main():
     # ---- GPU set-up
     from gpsmi import engine as E
     from gpsmi.acquisition import Acquisition
+    if a.rehearse:
+        local = local % E.device_count()
     cfg = E.Config(device=local)
     dev_name = E.device_name(local)
     acq = Acquisition(cfg)
@@ -239,6 +243,7 @@ def main():
     shard = prn_all[rank * 32 // world:(rank + 1) * 32 // world]
     f41 = [-5000.0 + 250.0 * i for i in range(41)]
     comm = d_send = d_recv = None
+    use_rccl = world > 1 and not a.rehearse
     if world > 1:
         import ctypes as C
         from gpsmi import _lib
@@ -249,9 +254,20 @@ def main():
         import torch
         tid = torch.from_numpy(idb)
         dist.broadcast(tid, 0)
-        comm = C.c_void_p()
-        E.check(lib.gpsmi_comm_create(E.ptr(idb), world, rank, local,
-                                      C.byref(comm)), 'comm_create')
+        collective = 'rehearsal: none'
+        if use_rccl:
+            comm = C.c_void_p()
+            rc = lib.gpsmi_comm_create(E.ptr(idb), world, rank, local, C.byref(comm))
+            ok = torch.tensor([1 if rc == 0 else 0])
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)        # all ranks agree on the path
+            if int(ok[0]) == 1:
+                collective = 'rccl all-gather over xGMI'
+            else:
+                err = lib.gpsmi_last_error().decode(errors='replace')
+                collective = f'gloo all-gather (RCCL init failed: {err})'
+                if rc == 0:
+                    lib.gpsmi_comm_destroy(comm)
+                comm, use_rccl = None, False
         cells = len(f41) * len(shard)
         d_send = E.DeviceBuffer(cells * 16, local)
         d_recv = E.DeviceBuffer(cells * 16 * world, local)
@@ -277,10 +293,14 @@ def main():
         trk.replay_run_async(d_iq.at(trk_base), nb)
         trk.replay_fetch_async(pin.array)
         acq.engine.wait()
-        if world > 1:
+        if use_rccl:
             E.check(lib.gpsmi_comm_allgather_peaks(
                 comm, d_send.ptr, d_recv.ptr, len(f41) * len(shard),
                 E.ptr(gathered)), 'allgather')
+        elif world > 1 and not a.rehearse:                 # labelled fallback, see `collective`
+            mine = torch.from_numpy(acq_pin.array.view(np.uint8).reshape(-1).copy())
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine)
         trk.wait()
         if record:
             t, c = trk.last_ms()
@@ -334,7 +354,7 @@ def main():
                 'channels': len(chans), 'blocks': nb, 'sample_rate_hz': 2048000,
                 'sharding': ('1 GPU' if world == 1 else
                              f'{world} ranks: stream sharded in time, '
-                             'acquisition sharded by SV + RCCL all-gather'),
+                             f'acquisition sharded by SV, peaks by {collective}'),
             },
             'x_realtime': round(value / 2.048, 1),
             'roofline': {

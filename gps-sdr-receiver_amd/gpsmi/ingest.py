@@ -1,0 +1,88 @@
+"""Ingest side of the receiver: the raw-file reader and the overflow-dropping
+ring buffer of reference src/gpsrecv.py:47-104, :153-186, with the sample decode
+(``(I + jQ)/127.5 - (1+1j)``, gpsrecv.py:170-172) done on the GPU so that only
+2 bytes per sample cross PCIe instead of 8."""
+from collections import deque
+
+import numpy as np
+
+from . import engine as E
+from .synth import raw_to_c64
+
+MAXBUFSIZE = 16                       # gpsrecv.py:47
+
+
+class RingBuffer:
+    """pushToBuffer / pullFromBuffer (gpsrecv.py:76-104): when all slots are
+    taken the whole buffer is dropped and the loss is reported with the next
+    block that is pulled."""
+
+    def __init__(self, maxsize=MAXBUFSIZE):
+        self.maxsize = maxsize
+        self.buf = deque([], maxlen=maxsize)
+        self.nbuf = 0
+        self.bufskip = 0
+
+    def push(self, data):
+        if self.nbuf >= self.maxsize:
+            self.buf.clear()
+            self.nbuf = 0
+            self.bufskip += self.maxsize
+        self.buf.append(data)
+        self.nbuf += 1
+
+    def pull(self):
+        """-> (data, skipped streams); ([], 0) when empty."""
+        try:
+            data = self.buf.popleft()
+            self.nbuf -= 1
+            skip, self.bufskip = self.bufskip, 0
+        except IndexError:
+            data, skip = [], 0
+        return data, skip
+
+
+def read_raw_blocks(path, ngps=65536, start_stream=0):
+    """streamData's file loop (gpsrecv.py:162-176): little-endian uint16
+    (Q<<8 | I) blocks of NGPS samples; a short last block ends the stream."""
+    with open(path, 'rb') as f:
+        for _ in range(start_stream):
+            np.fromfile(f, dtype=np.uint16, count=ngps)
+        while True:
+            raw = np.fromfile(f, dtype=np.uint16, count=ngps)
+            if len(raw) != ngps:
+                return
+            yield raw
+
+
+def decode_host(raw):
+    """The reference's own decode on the host (numpy)."""
+    return raw_to_c64(raw)
+
+
+class DeviceIngest:
+    """Raw blocks -> complex64 blocks resident in HBM: upload 2 B/sample, unpack
+    there (gpsmi_dev_unpack_u8iq, bit-identical to the numpy expression)."""
+
+    def __init__(self, n_blocks, ngps=65536, device=0):
+        self.ngps, self.device = ngps, device
+        self.n_blocks = n_blocks
+        self.d_raw = E.DeviceBuffer(ngps * 2, device)
+        self.d_iq = E.DeviceBuffer(n_blocks * ngps * 8, device)
+
+    def put(self, slot, raw):
+        """Decode one raw block into slot `slot`; returns its device pointer."""
+        raw = np.ascontiguousarray(raw, dtype=np.uint16)
+        if raw.size != self.ngps or not 0 <= slot < self.n_blocks:
+            raise ValueError('bad block size or slot')
+        self.d_raw.upload(raw)
+        dst = self.d_iq.at(slot * self.ngps * 8)
+        E.unpack_u8iq(dst, self.d_raw.ptr, self.ngps, self.device)
+        return dst
+
+    def get(self, slot):
+        return self.d_iq.download(np.complex64, self.ngps, slot * self.ngps * 8)
+
+    def free(self):
+        self.d_raw.free()
+        self.d_iq.free()
