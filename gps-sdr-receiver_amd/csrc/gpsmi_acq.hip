@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "gpsmi_common.h"
+#include "gpsmi_direct.h"
 #include "gpsmi_fft.h"
 
 namespace gpsmi {
@@ -154,6 +155,45 @@ __global__ __launch_bounds__(256) void acq_corr_kernel(
     }
 }
 
+// ---- general code length: wipe-off + fold in the time domain ----------------
+// x[bin][m] = (1/n_avg) sum_i iq[i L + m] exp(-j fl32(om t32[i L + m]))
+__global__ __launch_bounds__(256) void acq_fold_kernel(
+    const float2* __restrict__ iq, const float* __restrict__ t32,
+    const float* __restrict__ omega, int n_avg, int L, float2* __restrict__ xout) {
+    const int m = blockIdx.x * 256 + threadIdx.x, bin = blockIdx.y;
+    if (m >= L) return;
+    const float om = omega[bin];
+    float ar = 0.f, ai = 0.f;
+    for (int i = 0; i < n_avg; ++i) {
+        const int k = i * L + m;
+        const float2 v = iq[k];
+        float sn, co;
+        sincosf(__fmul_rn(om, t32[k]), &sn, &co);
+        ar += co * v.x + sn * v.y;
+        ai += co * v.y - sn * v.x;
+    }
+    const float sc = 1.0f / (float)n_avg;
+    xout[(size_t)bin * L + m] = make_float2(ar * sc, ai * sc);
+}
+
+__global__ void acq_cells_kernel(int* __restrict__ xsel, int* __restrict__ rsel,
+                                 const int* __restrict__ slot, int nsv, int ncell) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncell) return;
+    xsel[c] = c / nsv;                       // the bin's folded block
+    rsel[c] = slot[c % nsv];                 // the SV's replica
+}
+
+__global__ void acq_peaks_kernel(const DirStats* __restrict__ st, gpsmi_peak* __restrict__ out,
+                                 float2* __restrict__ nbr, int ncell) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncell) return;
+    gpsmi_peak p;
+    p.argmax = st[c].argmax; p.peak = st[c].peak; p.mean = st[c].mean; p.std = st[c].std;
+    out[c] = p;
+    if (nbr) nbr[c] = make_float2(st[c].lo, st[c].hi);
+}
+
 }  // namespace gpsmi
 
 using namespace gpsmi;
@@ -171,6 +211,13 @@ struct gpsmi_acq {
     float* d_omega = nullptr; int* d_slot = nullptr; gpsmi_peak* d_peaks = nullptr;
     size_t cell_cap = 0;
     float2* d_nbr = nullptr;
+    // direct (time-domain) path for code_samples != 2048
+    bool direct = false;
+    float* d_rep_time = nullptr;            // [GPSMI_MAX_PRN + 1][cs]
+    bool have_time[GPSMI_MAX_PRN + 1] = {};
+    float2* d_fold = nullptr; float* d_mag = nullptr; DirStats* d_stats = nullptr;
+    int* d_xsel = nullptr; int* d_rsel = nullptr;
+    size_t dir_bins = 0, dir_cells = 0;
     float last_ms = 0.f;
     bool pending = false;
 };
@@ -202,15 +249,16 @@ extern "C" {
 
 int gpsmi_acq_create(const gpsmi_cfg* cfg, gpsmi_acq** out) {
     GPSMI_REQUIRE(cfg && out, "null argument");
-    if (cfg->code_samples != kFftN)
-        return fail(GPSMI_E_UNSUPPORTED, "acquisition engine is built for code_samples = %d, got %d",
-                    kFftN, cfg->code_samples);
+    GPSMI_REQUIRE(cfg->code_samples >= 1024 && cfg->code_samples <= 65536 &&
+                      cfg->code_samples % 16 == 0,
+                  "code_samples must be a multiple of 16 in 1024..65536");
     GPSMI_REQUIRE(cfg->n_cyc >= 1 && cfg->n_cyc <= 64, "n_cyc out of range");
     GPSMI_HIP(hipSetDevice(cfg->device));
     gpsmi_acq* h = new (std::nothrow) gpsmi_acq();
     if (!h) return fail(GPSMI_E_NOMEM, "out of host memory");
     h->cfg = *cfg;
     *out = h;
+    h->direct = cfg->code_samples != kFftN;
     GPSMI_HIP(hipStreamCreate(&h->stream));
     GPSMI_HIP(hipEventCreate(&h->ev0));
     GPSMI_HIP(hipEventCreate(&h->ev1));
@@ -227,6 +275,9 @@ int gpsmi_acq_create(const gpsmi_cfg* cfg, gpsmi_acq** out) {
     GPSMI_HIP(hipMemcpy(h->d_t32, t32.data(), ngps * sizeof(float), hipMemcpyHostToDevice));
     GPSMI_HIP(hipMalloc((void**)&h->d_rep, (size_t)(GPSMI_MAX_PRN + 1) * kFftN * sizeof(float2)));
     GPSMI_HIP(hipMalloc((void**)&h->d_slot, (GPSMI_MAX_PRN + 1) * sizeof(int)));
+    if (h->direct)
+        GPSMI_HIP(hipMalloc((void**)&h->d_rep_time,
+                            (size_t)(GPSMI_MAX_PRN + 1) * cfg->code_samples * sizeof(float)));
     return GPSMI_OK;
 }
 
@@ -235,7 +286,8 @@ int gpsmi_acq_destroy(gpsmi_acq* h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* bufs[] = {h->d_tw, h->d_t32, h->d_rep, h->d_iq, h->d_spec, h->d_omega, h->d_slot,
-                    h->d_peaks, h->d_nbr};
+                    h->d_peaks, h->d_nbr, h->d_rep_time, h->d_fold, h->d_mag, h->d_stats,
+                    h->d_xsel, h->d_rsel};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -245,9 +297,21 @@ int gpsmi_acq_destroy(gpsmi_acq* h) {
     return GPSMI_OK;
 }
 
+int gpsmi_acq_set_replica_time(gpsmi_acq* h, int prn, const float* replica) {
+    GPSMI_REQUIRE(h && replica, "null argument");
+    GPSMI_REQUIRE(prn >= 1 && prn <= GPSMI_MAX_PRN, "prn out of range 1..37");
+    if (!h->direct) return GPSMI_OK;         // the FFT path has no use for it
+    GPSMI_HIP(hipSetDevice(h->cfg.device));
+    GPSMI_HIP(hipMemcpy(h->d_rep_time + (size_t)prn * h->cfg.code_samples, replica,
+                        (size_t)h->cfg.code_samples * sizeof(float), hipMemcpyHostToDevice));
+    h->have_time[prn] = true;
+    return GPSMI_OK;
+}
+
 int gpsmi_acq_set_replica(gpsmi_acq* h, int prn, const float* spectrum) {
     GPSMI_REQUIRE(h && spectrum, "null argument");
     GPSMI_REQUIRE(prn >= 1 && prn <= GPSMI_MAX_PRN, "prn out of range 1..37");
+    if (h->direct) return fail(GPSMI_E_STATE, "code_samples != 2048: use gpsmi_acq_set_replica_time");
     GPSMI_HIP(hipSetDevice(h->cfg.device));
     GPSMI_HIP(hipMemcpy(h->d_rep + (size_t)prn * kFftN, spectrum, kFftN * sizeof(float2),
                         hipMemcpyHostToDevice));
@@ -263,10 +327,11 @@ static int acq_search_impl(gpsmi_acq* h, const void* d_iq, size_t n, const int32
     GPSMI_REQUIRE(nsv >= 0 && nsv <= GPSMI_MAX_PRN, "nsv out of range");
     GPSMI_REQUIRE(nbins >= 0 && nbins <= 65535, "nbins out of range");
     GPSMI_REQUIRE(n_avg >= 1 && n_avg <= h->cfg.n_cyc, "n_avg out of range 1..n_cyc");
-    GPSMI_REQUIRE(n >= (size_t)n_avg * kFftN, "iq shorter than n_avg code periods");
+    const int cs = h->cfg.code_samples;
+    GPSMI_REQUIRE(n >= (size_t)n_avg * cs, "iq shorter than n_avg code periods");
     for (int i = 0; i < nsv; ++i) {
         GPSMI_REQUIRE(prn[i] >= 1 && prn[i] <= GPSMI_MAX_PRN, "prn out of range 1..37");
-        if (!h->have_rep[prn[i]])
+        if (!(h->direct ? h->have_time[prn[i]] : h->have_rep[prn[i]]))
             return fail(GPSMI_E_STATE, "no replica set for PRN %d", (int)prn[i]);
     }
     h->last_ms = 0.f;
@@ -281,11 +346,48 @@ static int acq_search_impl(gpsmi_acq* h, const void* d_iq, size_t n, const int32
     GPSMI_HIP(hipStreamSynchronize(h->stream));
     GPSMI_HIP(hipMemcpy(h->d_omega, om.data(), nbins * sizeof(float), hipMemcpyHostToDevice));
     GPSMI_HIP(hipMemcpy(h->d_slot, prn, nsv * sizeof(int), hipMemcpyHostToDevice));
+    if (h->direct) {
+        const size_t cells = (size_t)nbins * nsv;
+        if ((size_t)nbins > h->dir_bins) {
+            if (h->d_fold) GPSMI_HIP(hipFree(h->d_fold));
+            h->d_fold = nullptr; h->dir_bins = 0;
+            GPSMI_HIP(hipMalloc((void**)&h->d_fold, (size_t)nbins * cs * sizeof(float2)));
+            h->dir_bins = nbins;
+        }
+        if (cells > h->dir_cells) {
+            void* olds[] = {h->d_mag, h->d_stats, h->d_xsel, h->d_rsel};
+            for (void* p : olds)
+                if (p) GPSMI_HIP(hipFree(p));
+            h->d_mag = nullptr; h->d_stats = nullptr; h->d_xsel = h->d_rsel = nullptr;
+            h->dir_cells = 0;
+            GPSMI_HIP(hipMalloc((void**)&h->d_mag, cells * cs * sizeof(float)));
+            GPSMI_HIP(hipMalloc((void**)&h->d_stats, cells * sizeof(DirStats)));
+            GPSMI_HIP(hipMalloc((void**)&h->d_xsel, cells * sizeof(int)));
+            GPSMI_HIP(hipMalloc((void**)&h->d_rsel, cells * sizeof(int)));
+            h->dir_cells = cells;
+        }
+    }
     GPSMI_HIP(hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(acq_spectrum_kernel, dim3(nbins), dim3(256), 0, h->stream,
-                       (const float2*)d_iq, h->d_t32, h->d_omega, n_avg, h->d_spec, h->d_tw);
-    hipLaunchKernelGGL(acq_corr_kernel, dim3(nsv, nbins), dim3(256), 0, h->stream, h->d_spec,
-                       h->d_rep, h->d_slot, h->d_peaks, nsv, h->d_tw, nbr ? h->d_nbr : nullptr);
+    if (h->direct) {
+        const int ncell = nbins * nsv;
+        hipLaunchKernelGGL(acq_fold_kernel, dim3((cs + 255) / 256, nbins), dim3(256), 0, h->stream,
+                           (const float2*)d_iq, h->d_t32, h->d_omega, n_avg, cs, h->d_fold);
+        hipLaunchKernelGGL(acq_cells_kernel, dim3((ncell + 255) / 256), dim3(256), 0, h->stream,
+                           h->d_xsel, h->d_rsel, h->d_slot, nsv, ncell);
+        hipLaunchKernelGGL(circ_corr_direct_kernel,
+                           dim3((cs + kDirLagsPerWg - 1) / kDirLagsPerWg, ncell), dim3(256), 0,
+                           h->stream, h->d_fold, h->d_rep_time, h->d_xsel, h->d_rsel, cs, h->d_mag);
+        hipLaunchKernelGGL(corr_stats_kernel, dim3(ncell), dim3(256), 0, h->stream, h->d_mag, cs,
+                           h->d_stats);
+        hipLaunchKernelGGL(acq_peaks_kernel, dim3((ncell + 255) / 256), dim3(256), 0, h->stream,
+                           h->d_stats, h->d_peaks, nbr ? h->d_nbr : nullptr, ncell);
+    } else {
+        hipLaunchKernelGGL(acq_spectrum_kernel, dim3(nbins), dim3(256), 0, h->stream,
+                           (const float2*)d_iq, h->d_t32, h->d_omega, n_avg, h->d_spec, h->d_tw);
+        hipLaunchKernelGGL(acq_corr_kernel, dim3(nsv, nbins), dim3(256), 0, h->stream, h->d_spec,
+                           h->d_rep, h->d_slot, h->d_peaks, nsv, h->d_tw,
+                           nbr ? h->d_nbr : nullptr);
+    }
     GPSMI_HIP(hipGetLastError());
     GPSMI_HIP(hipEventRecord(h->ev1, h->stream));
     size_t bytes = (size_t)nbins * nsv * sizeof(gpsmi_peak);
@@ -332,9 +434,9 @@ int gpsmi_acq_search_ex(gpsmi_acq* h, const float* iq, size_t n, const int32_t* 
                         const double* freqs, int nbins, int n_avg, gpsmi_peak* out, float* nbr) {
     GPSMI_REQUIRE(h && iq && out, "null argument");
     GPSMI_REQUIRE(n_avg >= 1 && n_avg <= h->cfg.n_cyc, "n_avg out of range 1..n_cyc");
-    GPSMI_REQUIRE(n >= (size_t)n_avg * kFftN, "iq shorter than n_avg code periods");
+    GPSMI_REQUIRE(n >= (size_t)n_avg * h->cfg.code_samples, "iq shorter than n_avg code periods");
     GPSMI_HIP(hipSetDevice(h->cfg.device));
-    size_t need = (size_t)n_avg * kFftN;
+    size_t need = (size_t)n_avg * h->cfg.code_samples;
     if (need > h->iq_cap) {
         if (h->d_iq) GPSMI_HIP(hipFree(h->d_iq));
         h->d_iq = nullptr; h->iq_cap = 0;

@@ -59,6 +59,7 @@ EXPORTS = [
     'gpsmi_host_alloc', 'gpsmi_host_free',
     'gpsmi_dev_unpack_u8iq',
     'gpsmi_acq_create', 'gpsmi_acq_destroy', 'gpsmi_acq_set_replica',
+    'gpsmi_acq_set_replica_time',
     'gpsmi_acq_search', 'gpsmi_acq_search_dev', 'gpsmi_acq_search_ex',
     'gpsmi_acq_search_dev_async', 'gpsmi_acq_wait',
     'gpsmi_acq_last_ms',
@@ -107,6 +108,7 @@ def load():
         'gpsmi_acq_create': [P(Cfg), P(vp)],
         'gpsmi_acq_destroy': [vp],
         'gpsmi_acq_set_replica': [vp, C.c_int, vp],
+        'gpsmi_acq_set_replica_time': [vp, C.c_int, vp],
         'gpsmi_acq_search': [vp, vp, sz, vp, C.c_int, vp, C.c_int, C.c_int, vp],
         'gpsmi_acq_search_dev': [vp, vp, sz, vp, C.c_int, vp, C.c_int, C.c_int,
                                  vp, vp],

@@ -147,9 +147,15 @@ class AcqEngine:
               'gpsmi_acq_create')
         self.h = h
         for p in prns:
-            spec = _spectrum_c64(p, self.cfg.code_samples)
-            check(self.lib.gpsmi_acq_set_replica(self.h, p, ptr(spec)),
-                  'gpsmi_acq_set_replica')
+            if self.cfg.code_samples == 2048:
+                spec = _spectrum_c64(p, self.cfg.code_samples)
+                check(self.lib.gpsmi_acq_set_replica(self.h, p, ptr(spec)),
+                      'gpsmi_acq_set_replica')
+            else:                      # time-domain correlation for other code lengths
+                rep = np.ascontiguousarray(
+                    codes.code_replica(p, self.cfg.code_samples).astype(np.float32))
+                check(self.lib.gpsmi_acq_set_replica_time(self.h, p, ptr(rep)),
+                      'gpsmi_acq_set_replica_time')
 
     def search(self, iq, prns, freqs, n_avg, out_dev=None):
         """iq: complex64 numpy array (host) or a (c_void_p, n) device pair.

@@ -44,7 +44,8 @@ extern "C" {
 
 /* Module constants of gpsglob.py:35-131 that the path depends on. */
 typedef struct gpsmi_cfg {
-    int32_t code_samples;    /* CODE_SAMPLES  gpsglob.py:119  (power of two)     */
+    int32_t code_samples;    /* CODE_SAMPLES  gpsglob.py:119; 2048 takes the LDS-FFT */
+                             /*   path, any other multiple of 16 the direct one   */
     int32_t n_cyc;           /* N_CYC         gpsglob.py:122                     */
     int32_t corr_avg;        /* CORR_AVG      gpsglob.py:63                      */
     int32_t sweep_corr_avg;  /* SWEEP_CORR_AVG gpsglob.py:67                     */
@@ -100,6 +101,9 @@ int gpsmi_acq_destroy(gpsmi_acq* h);
 /* FFT_CACODE[prn] (gpsrecv.py:574-577): spectrum of the sampled replica,
  * complex64 [code_samples]; the host computes it once (gpsmi.codes).         */
 int gpsmi_acq_set_replica(gpsmi_acq* h, int prn, const float* spectrum_c64);
+/* GPSCacode(prn) itself, float32 [code_samples]: needed when code_samples is not
+ * 2048 (the correlation is then done in the time domain).       */
+int gpsmi_acq_set_replica_time(gpsmi_acq* h, int prn, const float* replica_f32);
 /* Search nbins Doppler bins x nsv satellites on the first n_avg code periods of
  * iq.  freqs_hz[b] are the bin frequencies exactly as the reference steps them
  * (python floats); out is [nbins][nsv].  iq: host complex64, n >= n_avg*cs.   */

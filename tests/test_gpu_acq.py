@@ -133,3 +133,37 @@ def test_device_resident_input_equals_host_input(acq):
     b = acq.engine.search((buf.ptr, data.size), [4, 5, 6], f, 4)
     assert a.tobytes() == b.tobytes()
     buf.free()
+
+
+# ---- BASELINE config 5: CODE_SAMPLES = 16368, N_CYC = 8 (time-domain correlation) ----
+
+@pytest.fixture(scope='module')
+def acq_hirate():
+    from gpsmi.acquisition import Acquisition
+    from gpsmi.engine import Config
+    a = Acquisition(Config(code_samples=16368, n_cyc=8))
+    yield a
+    a.engine.close()
+
+
+def test_hirate_cfg2_surface(acq_hirate, golden_hirate):
+    """32 SV x 41 bins x 1 ms at 16.368 Msps against the reference's own surface."""
+    f41 = [-5000.0 + 250.0 * i for i in range(41)]
+    t = acq_hirate.search_table(scene_blocks('hirate', 0, 1)[0], list(range(1, 33)),
+                                f41, 1)
+    _check(t, golden_hirate, 'cfg2_')
+
+
+def test_hirate_sweep_all_sats_loop(acq_hirate, golden_hirate):
+    g = golden_hirate
+    acq = acq_hirate
+    sat_lst, found, freq = list(range(2, 33)), [], acq.cfg.min_freq
+    blocks = scene_blocks('hirate', 0, 5)
+    for b in range(5):
+        ready, freq, found = acq.sweepAllSats(blocks[b], freq, sat_lst, found,
+                                              itSweep=acq.cfg.it_sweep_all)
+        assert (float(ready), freq, len(found)) == tuple(g['sweep_calls'][b])
+    mine = np.array(found, dtype=np.float64)
+    ref = g['sweep_found']
+    assert np.array_equal(mine[:, 1:], ref[:, 1:])
+    np.testing.assert_allclose(mine[:, 0], ref[:, 0], rtol=RTOL)
