@@ -32,7 +32,7 @@ struct DirStats {            // per cell
 
 // x: [nvec][L] complex; rep: [slots][L] real; cell c uses x[xsel[c]] and
 // rep[rsel[c]]; mag: [ncell][L]
-__global__ __launch_bounds__(256) void circ_corr_direct_kernel(
+static __global__ __launch_bounds__(256) void circ_corr_direct_kernel(
     const float2* __restrict__ x, const float* __restrict__ rep, const int* __restrict__ xsel,
     const int* __restrict__ rsel, int L, float* __restrict__ mag) {
     __shared__ __attribute__((aligned(16))) float2 sx[kDirStep];
@@ -93,7 +93,7 @@ __device__ __forceinline__ float dir_wave_sum(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void corr_stats_kernel(const float* __restrict__ mag, int L,
+static __global__ __launch_bounds__(256) void corr_stats_kernel(const float* __restrict__ mag, int L,
                                                          DirStats* __restrict__ out) {
     __shared__ float red[16];
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, cell = blockIdx.x;

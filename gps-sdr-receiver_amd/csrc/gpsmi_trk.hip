@@ -107,6 +107,7 @@ __device__ inline double fit_code_phase(double lo, double pk, double hi, int mx)
 #include "gpsmi_trk_stream.h"
 #include "gpsmi_trk_stream_lds.h"
 #include "gpsmi_trk_corr.h"
+#include "gpsmi_trk_general.h"
 
 namespace gpsmi {
 
@@ -303,16 +304,34 @@ struct gpsmi_trk {
     bool replay_forced = false;
     bool timing_pending = false;
     int corr_cg = 6;
+    // code_samples != 2048: time-domain correlation + chunked correlator
+    bool general = false;
+    int nchunks = 1;
+    float2* d_fold = nullptr; float* d_mag = nullptr; DirStats* d_stats = nullptr;
+    int* d_xsel = nullptr; int* d_rsel = nullptr; float2* d_partial_g = nullptr;
     TrkParams P;
 };
 
 static int trk_reserve(gpsmi_trk* h, size_t njobs) {
     if (njobs <= h->njobs_cap) return GPSMI_OK;
-    void* olds[] = {h->d_tab_in, h->d_tab_out, h->d_forced, h->d_mid, h->d_partial, h->d_out};
+    void* olds[] = {h->d_tab_in, h->d_tab_out, h->d_forced, h->d_mid, h->d_partial, h->d_out,
+                    h->d_fold, h->d_mag, h->d_stats, h->d_xsel, h->d_rsel, h->d_partial_g};
     for (void* p : olds)
         if (p) GPSMI_HIP(hipFree(p));
     h->d_tab_in = h->d_tab_out = nullptr; h->d_forced = nullptr; h->d_mid = nullptr;
     h->d_partial = nullptr; h->d_out = nullptr; h->njobs_cap = 0;
+    h->d_fold = nullptr; h->d_mag = nullptr; h->d_stats = nullptr; h->d_xsel = h->d_rsel = nullptr;
+    h->d_partial_g = nullptr;
+    if (h->general) {
+        const size_t cs = h->cfg.code_samples;
+        GPSMI_HIP(hipMalloc((void**)&h->d_fold, njobs * cs * sizeof(float2)));
+        GPSMI_HIP(hipMalloc((void**)&h->d_mag, njobs * cs * sizeof(float)));
+        GPSMI_HIP(hipMalloc((void**)&h->d_stats, njobs * sizeof(DirStats)));
+        GPSMI_HIP(hipMalloc((void**)&h->d_xsel, njobs * sizeof(int)));
+        GPSMI_HIP(hipMalloc((void**)&h->d_rsel, njobs * sizeof(int)));
+        GPSMI_HIP(hipMalloc((void**)&h->d_partial_g,
+                            njobs * h->nchunks * (h->cfg.n_cyc + 1) * sizeof(float2)));
+    }
     GPSMI_HIP(hipMalloc((void**)&h->d_tab_in, njobs * sizeof(gpsmi_trk_state)));
     GPSMI_HIP(hipMalloc((void**)&h->d_tab_out, njobs * sizeof(gpsmi_trk_state)));
     GPSMI_HIP(hipMalloc((void**)&h->d_forced, njobs * sizeof(int)));
@@ -334,6 +353,45 @@ static int trk_launch(gpsmi_trk* h, const float2* d_iq, const gpsmi_trk_state* s
     const int nblocks = njobs / nch;
     const int ngroups = (nch + kGroupCh - 1) / kGroupCh;
     const dim3 sgrid(((nblocks + 7) / 8) * 8 * ngroups);
+    if (h->general) {
+        const int cs = P.cs;
+        hipLaunchKernelGGL(trk_fold_general_kernel, dim3((cs + 255) / 256, njobs), dim3(256), 0,
+                           h->stream, d_iq, h->d_t32, st_in, P, h->d_fold, h->d_xsel, h->d_rsel,
+                           h->d_mid);
+        hipLaunchKernelGGL(circ_corr_direct_kernel,
+                           dim3((cs + kDirLagsPerWg - 1) / kDirLagsPerWg, njobs), dim3(256), 0,
+                           h->stream, h->d_fold, h->d_code, h->d_xsel, h->d_rsel, cs, h->d_mag);
+        hipLaunchKernelGGL(corr_stats_kernel, dim3(njobs), dim3(256), 0, h->stream, h->d_mag, cs,
+                           h->d_stats);
+        hipLaunchKernelGGL(trk_decide_kernel, dim3((njobs + 255) / 256), dim3(256), 0, h->stream,
+                           h->d_stats, forced, P, njobs, h->d_out, h->d_mid);
+        GPSMI_HIP(hipEventRecord(h->ev[1], h->stream));
+        const dim3 grid(sgrid.x, h->nchunks), block(kStreamThreads);
+        switch (P.n_cyc) {
+            case 32:
+                hipLaunchKernelGGL((trk_stream_kernel<32, true>), grid, block, 0, h->stream, d_iq,
+                                   st_in, h->d_mid, h->d_code, P, ngroups, nblocks, h->d_partial_g);
+                break;
+            case 16:
+                hipLaunchKernelGGL((trk_stream_kernel<16, true>), grid, block, 0, h->stream, d_iq,
+                                   st_in, h->d_mid, h->d_code, P, ngroups, nblocks, h->d_partial_g);
+                break;
+            default:
+                hipLaunchKernelGGL((trk_stream_kernel<8, true>), grid, block, 0, h->stream, d_iq,
+                                   st_in, h->d_mid, h->d_code, P, ngroups, nblocks, h->d_partial_g);
+                break;
+        }
+        const int per_job = P.n_cyc + 1;
+        hipLaunchKernelGGL(trk_partial_reduce_kernel, dim3((njobs * per_job + 255) / 256), dim3(256),
+                           0, h->stream, h->d_partial_g, h->nchunks, per_job, njobs, h->d_mid,
+                           h->d_partial);
+        GPSMI_HIP(hipEventRecord(h->ev[2], h->stream));
+        hipLaunchKernelGGL(trk_epilogue_kernel, dim3((njobs + 3) / 4), dim3(256), 0, h->stream,
+                           st_in, st_out, h->d_mid, h->d_partial, P, njobs, h->d_out);
+        GPSMI_HIP(hipGetLastError());
+        GPSMI_HIP(hipEventRecord(h->ev[3], h->stream));
+        return GPSMI_OK;
+    }
     {
         // channels per correlation workgroup: fewer channels = fewer live accumulators
         // = more workgroups per CU for the barrier-heavy FFT phase (GPSMI_CORR_CG to tune)
@@ -415,9 +473,9 @@ extern "C" {
 int gpsmi_trk_create(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk** out) {
     GPSMI_REQUIRE(cfg && out, "null argument");
     GPSMI_REQUIRE(max_ch >= 1 && max_ch <= 4096, "max_ch out of range");
-    if (cfg->code_samples != kFftN)
-        return fail(GPSMI_E_UNSUPPORTED, "tracking engine is built for code_samples = %d, got %d",
-                    kFftN, cfg->code_samples);
+    GPSMI_REQUIRE(cfg->code_samples >= 1024 && cfg->code_samples <= 65536 &&
+                      cfg->code_samples % 16 == 0,
+                  "code_samples must be a multiple of 16 in 1024..65536");
     GPSMI_REQUIRE(cfg->n_cyc == 8 || cfg->n_cyc == 16 || cfg->n_cyc == 32,
                   "n_cyc must be 8, 16 or 32 (gpsglob.py:122)");
     GPSMI_REQUIRE(cfg->corr_avg >= 1, "corr_avg must be >= 1");
@@ -427,6 +485,8 @@ int gpsmi_trk_create(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk** out) {
     if (!h) return fail(GPSMI_E_NOMEM, "out of host memory");
     h->cfg = *cfg;
     h->max_ch = max_ch;
+    h->general = cfg->code_samples != kFftN;
+    h->nchunks = (cfg->code_samples + kFftN - 1) / kFftN;
     *out = h;
     GPSMI_HIP(hipStreamCreate(&h->stream));
     for (auto& e : h->ev) GPSMI_HIP(hipEventCreate(&e));
@@ -441,7 +501,9 @@ int gpsmi_trk_create(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk** out) {
     GPSMI_HIP(hipMalloc((void**)&h->d_t32, ngps * sizeof(float)));
     GPSMI_HIP(hipMemcpy(h->d_t32, t32.data(), ngps * sizeof(float), hipMemcpyHostToDevice));
     GPSMI_HIP(hipMalloc((void**)&h->d_rep, (size_t)(GPSMI_MAX_PRN + 1) * kFftN * sizeof(float2)));
-    GPSMI_HIP(hipMalloc((void**)&h->d_code, (size_t)(GPSMI_MAX_PRN + 1) * kFftN * sizeof(float)));
+    const size_t code_bytes = (size_t)(GPSMI_MAX_PRN + 1) * cfg->code_samples * sizeof(float);
+    GPSMI_HIP(hipMalloc((void**)&h->d_code, code_bytes));
+    GPSMI_HIP(hipMemset(h->d_code, 0, code_bytes));          // slot 0: closed channels
     GPSMI_HIP(hipMalloc((void**)&h->d_block, (size_t)ngps * sizeof(float2)));
     GPSMI_HIP(hipMalloc((void**)&h->d_state, max_ch * sizeof(gpsmi_trk_state)));
     h->h_state.assign(max_ch, gpsmi_trk_state{});
@@ -465,7 +527,8 @@ int gpsmi_trk_destroy(gpsmi_trk* h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* bufs[] = {h->d_tw, h->d_t32, h->d_rep, h->d_code, h->d_block, h->d_state, h->d_tab_in,
-                    h->d_tab_out, h->d_forced, h->d_mid, h->d_partial, h->d_out};
+                    h->d_tab_out, h->d_forced, h->d_mid, h->d_partial, h->d_out, h->d_fold,
+                    h->d_mag, h->d_stats, h->d_xsel, h->d_rsel, h->d_partial_g};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto e : h->ev)
@@ -476,13 +539,15 @@ int gpsmi_trk_destroy(gpsmi_trk* h) {
 }
 
 int gpsmi_trk_set_replica(gpsmi_trk* h, int prn, const float* replica, const float* spectrum) {
-    GPSMI_REQUIRE(h && replica && spectrum, "null argument");
+    GPSMI_REQUIRE(h && replica && (spectrum || h->general), "null argument");
     GPSMI_REQUIRE(prn >= 1 && prn <= GPSMI_MAX_PRN, "prn out of range 1..37");
     GPSMI_HIP(hipSetDevice(h->cfg.device));
-    GPSMI_HIP(hipMemcpy(h->d_code + (size_t)prn * kFftN, replica, kFftN * sizeof(float),
+    const size_t cs = h->cfg.code_samples;
+    GPSMI_HIP(hipMemcpy(h->d_code + (size_t)prn * cs, replica, cs * sizeof(float),
                         hipMemcpyHostToDevice));
-    GPSMI_HIP(hipMemcpy(h->d_rep + (size_t)prn * kFftN, spectrum, kFftN * sizeof(float2),
-                        hipMemcpyHostToDevice));
+    if (!h->general)                       // the time-domain path needs no spectrum
+        GPSMI_HIP(hipMemcpy(h->d_rep + (size_t)prn * kFftN, spectrum, kFftN * sizeof(float2),
+                            hipMemcpyHostToDevice));
     h->have_rep[prn] = true;
     return GPSMI_OK;
 }

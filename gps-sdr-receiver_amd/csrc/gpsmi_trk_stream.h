@@ -120,7 +120,12 @@ __device__ __forceinline__ void mixed_fix(v2f& acc, const v2f* B, const v2f* df,
     acc += t0 + t1;
 }
 
-template <int NC>
+// GEN = false: code period of exactly 2048 samples (one chunk, the hot path).
+// GEN = true: any code length that is a multiple of 16; blockIdx.y selects a chunk
+// of 2048 positions of the code period, positions beyond CS are masked (B = 0,
+// their loads redirected to position 0 of the row) and each chunk writes its own
+// partial sums (partial[job][chunk][NC+1], added up by trk_partial_reduce_kernel).
+template <int NC, bool GEN = false>
 __global__ __launch_bounds__(kStreamThreads, 2) void trk_stream_kernel(
     const float2* __restrict__ iq, const gpsmi_trk_state* __restrict__ st_in,
     const JobMid* __restrict__ mid, const float* __restrict__ code, TrkParams P,
@@ -141,7 +146,8 @@ __global__ __launch_bounds__(kStreamThreads, 2) void trk_stream_kernel(
     if (b >= nblocks) return;
 
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    const int cs = kFftN;
+    const int cs = GEN ? P.cs : kFftN;
+    const int chunk = GEN ? (int)blockIdx.y : 0, nchunks = GEN ? (int)gridDim.y : 1;
     const float2* blk = iq + (size_t)b * ((size_t)cs * NC);
     const float inv_fs = 1.0f / (1000.0f * (float)cs);
 
@@ -166,7 +172,10 @@ __global__ __launch_bounds__(kStreamThreads, 2) void trk_stream_kernel(
     v2f B[kGroupCh][kJ];
     int kcls[kGroupCh], istar[kGroupCh];
     unsigned long long lm0[kGroupCh], lm1[kGroupCh];
-    const int mbase = 512 * wave + 2 * lane;                  // m = mbase + 128 i + e
+    const int mbase = 2048 * chunk + 512 * wave + 2 * lane;   // m = mbase + 128 i + e
+    int xo[4];                                                // GEN: load offsets in the row
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xo[i] = (mbase + 128 * i < cs) ? mbase + 128 * i : 0;
 #pragma unroll
     for (int c = 0; c < kGroupCh; ++c) {
         const int cidx = g * kGroupCh + c;
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(kStreamThreads, 2) void trk_stream_kernel(
         float2 z0 = phasor_rev(rev0);
         const float2 rT = rot[c][kJ];
         // wave-uniform class: 0 all hi (m >= d), 1 all lo, 2 mixed
-        const int w0 = 512 * wave;
+        const int w0 = 2048 * chunk + 512 * wave;
         int k = (s.d <= w0) ? 0 : (s.d >= w0 + 512 ? 1 : 2);
         if (!s.active) k = 0;
         k = __builtin_amdgcn_readfirstlane(k);
@@ -199,7 +208,14 @@ __global__ __launch_bounds__(kStreamThreads, 2) void trk_stream_kernel(
                 const bool lo = m < s.d;
                 z = make_float2(lo ? zl.x : z.x, lo ? zl.y : z.y);
             }
-            const float v = s.active ? cv[(m - s.d) & (cs - 1)] : 0.f;
+            float v;
+            if (GEN) {
+                int idx = m - s.d;
+                if (idx < 0) idx += cs;
+                v = (s.active && m < cs) ? cv[idx] : 0.f;
+            } else {
+                v = s.active ? cv[(m - s.d) & (cs - 1)] : 0.f;
+            }
             B[c][j] = v2f{v * z.x, v * z.y};
         }
         // mixed wave: boundary chunk and the lane masks of its two elements
@@ -225,10 +241,13 @@ __global__ __launch_bounds__(kStreamThreads, 2) void trk_stream_kernel(
     v2f xb[4][kJ];
     auto load_row = [&](v2f* dst, int r) {
         if (r < NC) {
-            const float4* p = reinterpret_cast<const float4*>(blk + (size_t)r * cs + mbase);
+            const float2* row = blk + (size_t)r * cs;
+            const float4* p = reinterpret_cast<const float4*>(row + mbase);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                float4 v = p[i * 64];                          // 128 samples = 64 float4 apart
+                float4 v;
+                if (GEN) v = *reinterpret_cast<const float4*>(row + xo[i]);
+                else v = p[i * 64];                            // 128 samples = 64 float4 apart
                 dst[2 * i] = v2f{v.x, v.y};
                 dst[2 * i + 1] = v2f{v.z, v.w};
             }
@@ -358,7 +377,8 @@ __global__ __launch_bounds__(kStreamThreads, 2) void trk_stream_kernel(
         // U[q] = exp(-j om q T), angle reduced in double (in revolutions)
         const double rev = (double)s.om * 0.15915494309189533576888376337251 * (double)q * 1.0e-3;
         const float2 u = phasor_rev((float)(rev - rint(rev)));          // (cos a, -sin a)
-        partial[(size_t)s.job * (NC + 1) + o] = make_float2(sx * u.x - sy * u.y, sy * u.x + sx * u.y);
+        partial[((size_t)s.job * nchunks + chunk) * (NC + 1) + o] =
+            make_float2(sx * u.x - sy * u.y, sy * u.x + sx * u.y);
     }
 }
 

@@ -194,7 +194,8 @@ typedef struct gpsmi_trk_out {
 
 int gpsmi_trk_create(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk** out);
 int gpsmi_trk_destroy(gpsmi_trk* h);
-/* GPSCacode(prn) as float32 [code_samples] and its spectrum, complex64.       */
+/* GPSCacode(prn) as float32 [code_samples] and its spectrum, complex64 (the
+ * spectrum is used, and required, only when code_samples == 2048).            */
 int gpsmi_trk_set_replica(gpsmi_trk* h, int prn, const float* replica_f32,
                           const float* spectrum_c64);
 /* ('initInst',(satNo,freq,delay)) of gpsrecv.py:312-321.                      */

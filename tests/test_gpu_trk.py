@@ -19,16 +19,12 @@ def _open_all(eng, g):
     return len(g['trk_init'])
 
 
-@pytest.fixture(scope='module')
-def closed_loop(golden_default):
-    """Run the closed loop once over the fixture blocks; keep every output and
-    the state at the start of every block."""
+def _run_closed_loop(g, config, cfg=None):
     from gpsmi.engine import TrkEngine, STATE_DTYPE
-    g = golden_default
     nch, nb = g['trk_delay'].shape
-    eng = TrkEngine(max_ch=nch)
+    eng = TrkEngine(cfg, max_ch=nch)
     _open_all(eng, g)
-    blocks = scene_blocks('default', 5, nb)
+    blocks = scene_blocks(config, 5, nb)
     outs, states = [], []
     for i in range(nb):
         st = np.zeros(nch, dtype=STATE_DTYPE)
@@ -36,14 +32,52 @@ def closed_loop(golden_default):
             st[c] = eng.get_state(c)
         states.append(st)
         outs.append(eng.process(blocks[i]))
-    yield eng, np.array(outs), np.array(states), blocks
-    eng.close()
+    return eng, np.array(outs), np.array(states), blocks
+
+
+@pytest.fixture(scope='module')
+def closed_loop(golden_default):
+    """Run the closed loop once over the fixture blocks; keep every output and
+    the state at the start of every block."""
+    r = _run_closed_loop(golden_default, 'default')
+    yield r
+    r[0].close()
+
+
+@pytest.fixture(scope='module')
+def closed_loop_hirate(golden_hirate):
+    """BASELINE config 5: CODE_SAMPLES = 16368, N_CYC = 8 (time-domain correlation,
+    chunked correlator)."""
+    from gpsmi.engine import Config
+    r = _run_closed_loop(golden_hirate, 'hirate', Config(code_samples=16368, n_cyc=8))
+    yield r
+    r[0].close()
 
 
 def test_closed_loop_matches_reference(closed_loop, golden_default):
+    _check_closed_loop(closed_loop[1], golden_default)
+
+
+def test_hirate_closed_loop_matches_reference(closed_loop_hirate, golden_hirate):
+    _check_closed_loop(closed_loop_hirate[1], golden_hirate)
+
+
+def test_hirate_replay_reproduces_closed_loop(closed_loop_hirate):
+    from gpsmi.engine import DeviceBuffer
+    eng, outs, states, blocks = closed_loop_hirate
+    nb, nch = outs.shape
+    buf = DeviceBuffer(nb * blocks[0].nbytes)
+    for i, b in enumerate(blocks):
+        buf.upload(b, i * b.nbytes)
+    rep = eng.replay(buf.ptr, nb, states, outs['delay_used'])
+    rep2 = eng.replay(buf.ptr, 6, states[:6], None)
+    buf.free()
+    assert rep.tobytes() == outs.tobytes()
+    assert rep2.tobytes() == outs[:6].tobytes()
+
+
+def _check_closed_loop(outs, g):
     from gpsmi.engine import dumps_of
-    g = golden_default
-    _, outs, _, _ = closed_loop
     nb, nch = outs.shape
     for c in range(nch):
         for i in range(nb):
