@@ -16,19 +16,22 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--blocks', type=int, default=1024)
 ap.add_argument('--channels', type=int, default=12)
 ap.add_argument('--iters', type=int, default=20)
+ap.add_argument('--code-samples', type=int, default=2048)
+ap.add_argument('--n-cyc', type=int, default=32)
 a = ap.parse_args()
 
-NGPS = 65536
+CS = a.code_samples
+NGPS = CS * a.n_cyc
 nb, nch = a.blocks, a.channels
 rng = np.random.default_rng(1)
-trk = E.TrkEngine(max_ch=nch)
+trk = E.TrkEngine(E.Config(code_samples=CS, n_cyc=a.n_cyc), max_ch=nch)
 buf = E.DeviceBuffer(nb * NGPS * 8)
-chunk = (rng.standard_normal((64, NGPS, 2)) * 0.25).astype(np.float32)
-for i in range(0, nb, 64):
-    n = min(64, nb - i)
+chunk = (rng.standard_normal((16, NGPS, 2)) * 0.25).astype(np.float32)
+for i in range(0, nb, 16):
+    n = min(16, nb - i)
     buf.upload(chunk[:n], i * NGPS * 8)
 for c in range(nch):
-    trk.open(c, 2 + c, -4000.0 + 700.0 * c, (137 * c + 11) % 2048)
+    trk.open(c, 2 + c, -4000.0 + 700.0 * c, (1137 * c + 11) % CS)
 st = np.zeros((nb, nch), dtype=E.STATE_DTYPE)
 for c in range(nch):
     st[:, c] = trk.get_state(c)
@@ -43,6 +46,6 @@ for i in range(a.iters + 3):
         tot.append(t)
         cor.append(c)
 gb = nb * NGPS * 8 / 1e9
-print(f'blocks {nb} channels {nch}: correlator {np.median(cor):.4f} ms '
+print(f'cs {CS} n_cyc {a.n_cyc} blocks {nb} channels {nch}: correlator {np.median(cor):.4f} ms '
       f'({gb / np.median(cor) * 1e3:.0f} GB/s, min {min(cor):.4f}), '
       f'all tracking kernels {np.median(tot):.4f} ms')
