@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void acq_spectrum_kernel(
         for (int r = 0; r < 8; ++r) {
             int k = i * kFftN + t + 256 * r;
             float2 x = iq[k];
-            float p = __fmul_rn(om, t32[k]);      // float32 phase argument, phase0 = 0
+            float p = mul_rn(om, t32[k]);      // float32 phase argument, phase0 = 0
             float s, c;
             sincosf(p, &s, &c);
             // factor = (c, -s); factor * x as numpy multiplies complex64
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void acq_fold_kernel(
         const int k = i * L + m;
         const float2 v = iq[k];
         float sn, co;
-        sincosf(__fmul_rn(om, t32[k]), &sn, &co);
+        sincosf(mul_rn(om, t32[k]), &sn, &co);
         ar += co * v.x + sn * v.y;
         ai += co * v.y - sn * v.x;
     }

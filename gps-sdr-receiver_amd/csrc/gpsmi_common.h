@@ -32,4 +32,14 @@ void make_twiddles(std::vector<float2>& tw);
 
 inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
+// Single float32 operations that are never fused into a multiply-add, for code that
+// restates the reference's numpy float32 arithmetic step by step.  (HIP's
+// __fmul_rn/__fadd_rn are plain operators compiled with contraction allowed: hipcc
+// fuses __fadd_rn(a, __fmul_rn(b, c)) into one v_fma.)
+#pragma clang fp contract(off)
+__device__ __host__ inline float mul_rn(float a, float b) { return a * b; }
+__device__ __host__ inline float add_rn(float a, float b) { return a + b; }
+__device__ __host__ inline float sub_rn(float a, float b) { return a - b; }
+#pragma clang fp contract(fast)
+
 }  // namespace gpsmi

@@ -5,6 +5,10 @@
 
 #include "gpsmi_common.h"
 
+// the unpack arithmetic mirrors numpy step by step: no fused multiply-add
+// (mul_rn/sub_rn of gpsmi_common.h are never contracted)
+#pragma clang fp contract(off)
+
 namespace gpsmi {
 
 char* last_error_buf() {
@@ -41,8 +45,8 @@ __global__ __launch_bounds__(256) void unpack_u8iq_kernel(float2* __restrict__ o
     for (; i < n; i += stride) {
         unsigned v = raw[i];
         const float scl = 1.0f / 127.5f;
-        float re = __fsub_rn(__fmul_rn((float)(v & 0xFF), scl), 1.0f);
-        float im = __fsub_rn(__fmul_rn((float)(v >> 8), scl), 1.0f);
+        float re = sub_rn(mul_rn((float)(v & 0xFF), scl), 1.0f);
+        float im = sub_rn(mul_rn((float)(v >> 8), scl), 1.0f);
         out[i] = make_float2(re, im);
     }
 }

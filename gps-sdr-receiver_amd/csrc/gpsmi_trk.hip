@@ -33,6 +33,11 @@
 #include "gpsmi_common.h"
 #include "gpsmi_fft.h"
 
+// Code that restates the reference's float32 arithmetic step by step (the phase
+// argument of the carrier, the PLL, numpy's summation order) must not be fused into
+// multiply-adds (hipcc contracts by default; see mul_rn/add_rn in gpsmi_common.h).  The streaming kernels (included below) keep the default.
+#pragma clang fp contract(off)
+
 namespace gpsmi {
 
 constexpr float kTwoPiF = 6.28318530717958647692f;   // float32(2*pi), numpy's weak-scalar cast
@@ -79,17 +84,12 @@ __device__ __forceinline__ void wave_argmax_t(float& v, int& i) {
 // omega as the reference forms 2*pi*freq for a float32 FREQ (numpy >= 2):
 // float32(2*pi) * freq in float32.
 __device__ __host__ __forceinline__ float omega_of(float freq) {
-#ifdef __HIP_DEVICE_COMPILE__
-    return __fmul_rn(kTwoPiF, freq);
-#else
-    volatile float w = kTwoPiF * freq;
-    return w;
-#endif
+    return mul_rn(kTwoPiF, freq);
 }
 
 // carrier factor exp(-j(phase + omega t[k])) with the float32 phase argument
 __device__ __forceinline__ float2 wipe(float2 x, float phase, float om, float tk) {
-    float p = __fadd_rn(phase, __fmul_rn(om, tk));
+    float p = add_rn(phase, mul_rn(om, tk));
     float s, c;
     sincosf(p, &s, &c);
     return make_float2(c * x.x + s * x.y, c * x.y - s * x.x);
@@ -104,10 +104,12 @@ __device__ inline double fit_code_phase(double lo, double pk, double hi, int mx)
 
 }  // namespace gpsmi
 
+#pragma clang fp contract(fast)
 #include "gpsmi_trk_stream.h"
 #include "gpsmi_trk_stream_lds.h"
 #include "gpsmi_trk_corr.h"
 #include "gpsmi_trk_general.h"
+#pragma clang fp contract(off)
 
 namespace gpsmi {
 
@@ -116,17 +118,17 @@ namespace gpsmi {
 __device__ inline float np_sum_f32(const float* a, int n) {
     if (n < 8) {
         float r = 0.f;
-        for (int i = 0; i < n; ++i) r = __fadd_rn(r, a[i]);
+        for (int i = 0; i < n; ++i) r = add_rn(r, a[i]);
         return r;
     }
     float r[8];
     for (int j = 0; j < 8; ++j) r[j] = a[j];
     int i = 8;
     for (; i < n - (n % 8); i += 8)
-        for (int j = 0; j < 8; ++j) r[j] = __fadd_rn(r[j], a[i + j]);
-    float res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
-                          __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
-    for (; i < n; ++i) res = __fadd_rn(res, a[i]);
+        for (int j = 0; j < 8; ++j) r[j] = add_rn(r[j], a[i + j]);
+    float res = add_rn(add_rn(add_rn(r[0], r[1]), add_rn(r[2], r[3])),
+                          add_rn(add_rn(r[4], r[5]), add_rn(r[6], r[7])));
+    for (; i < n; ++i) res = add_rn(res, a[i]);
     return res;
 }
 
@@ -193,8 +195,8 @@ __global__ __launch_bounds__(256) void trk_epilogue_kernel(
     __builtin_amdgcn_wave_barrier();
     const float mmean = np_sum_f32(s_mag[wave], nd) / (float)nd;
     {
-        const float e = __fsub_rn(mag, mmean);
-        if (lane < nd) s_dev[wave][lane] = __fmul_rn(e, e);
+        const float e = sub_rn(mag, mmean);
+        if (lane < nd) s_dev[wave][lane] = mul_rn(e, e);
     }
     __builtin_amdgcn_wave_barrier();
     const float sdev = sqrtf(np_sum_f32(s_dev[wave], nd) / (float)nd);
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(256) void trk_epilogue_kernel(
     const float ph_prev = __shfl_up(ph, 1, 64);
     float jump = 0.f;
     if (lane >= 1 && lane < nd) {
-        const float delta = __fsub_rn(ph, ph_prev);
+        const float delta = sub_rn(ph, ph_prev);
         if (fabsf(delta) > 2.0f) jump = (delta > 0.f) ? -1.f : 1.f;
     }
 #pragma unroll
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(256) void trk_epilogue_kernel(
         const float v = __shfl_up(jump, o2, 64);
         if (lane >= o2) jump += v;
     }
-    const float real = (lane == 0) ? ph : __fadd_rn(ph, __fmul_rn(jump, kPiF));
+    const float real = (lane == 0) ? ph : add_rn(ph, mul_rn(jump, kPiF));
     if (lane < nd) s_real[wave][lane] = real;
     __builtin_amdgcn_wave_barrier();
     const float offset = np_sum_f32(s_real[wave] + (nd - 4), 4) / 4.0f;
@@ -223,14 +225,14 @@ __global__ __launch_bounds__(256) void trk_epilogue_kernel(
     float df;
     if (locked) {
         const float mean_df = np_sum_f32(s_df[wave], df_len) / (float)df_len;
-        df = __fadd_rn(pdev, mean_df);                 // DF_GAIN2 = 1
+        df = add_rn(pdev, mean_df);                 // DF_GAIN2 = 1
         if (fabsf(df) > max_df) df = (df > 0.f ? 1.f : -1.f) * max_df;
         const int shift = df_len >= P.df_no ? 1 : 0;   // drop the oldest entry
         new_len = df_len - shift + 1;
         for (int i = lane; i < new_len - 1; i += 64) so.df[i] = s_df[wave][i + shift];
         if (lane == 0) so.df[new_len - 1] = df;
     } else {
-        df = __fmul_rn(10.0f, pdev);                   // DF_GAIN1 = 10
+        df = mul_rn(10.0f, pdev);                   // DF_GAIN1 = 10
         new_len = 1;
         if (lane == 0) so.df[0] = df;
     }
@@ -238,11 +240,11 @@ __global__ __launch_bounds__(256) void trk_epilogue_kernel(
 
     // ---- state update (gpslib.py:1178 via :1345-1346, then :1205-1208)
     const float om = omega0 != 0.f ? omega0 : omega_of(freq0);
-    float phase = __fadd_rn(phase0, __fmul_rn(om, P.t_last));
+    float phase = add_rn(phase0, mul_rn(om, P.t_last));
     float mod = fmodf(phase, kTwoPiF);                 // np.remainder(phase, 2*pi)
-    if (mod != 0.f && mod < 0.f) mod = __fadd_rn(mod, kTwoPiF);
-    phase = __fadd_rn(mod, offset);
-    float freq = __fadd_rn(freq0, df);
+    if (mod != 0.f && mod < 0.f) mod = add_rn(mod, kTwoPiF);
+    phase = add_rn(mod, offset);
+    float freq = add_rn(freq0, df);
     float om_new = 0.f;                                // FREQ is float32 from here on ...
     if (freq > P.max_freq) { freq = P.max_freq; om_new = P.om_max; }   // ... unless clamped to
     else if (freq < P.min_freq) { freq = P.min_freq; om_new = P.om_min; }  // a Python float

@@ -20,11 +20,16 @@
 //    instruction of a wave reads 1 KiB contiguous, and for each channel all
 //    waves but the one containing d are purely hi or purely lo.  Pure waves
 //    accumulate acc[row] += B*x[row] (a lo wave's row r is window r-1, fixed up
-//    when the waves are combined); only the one mixed wave per channel selects
-//    between x[row] and x[row+1] per element.
+//    when the waves are combined).  The one mixed wave per channel does the same
+//    and then moves the lo part of the row into the accumulator of the row above
+//    (window r-1): it sums the shorter side of the boundary again (one or two
+//    packed complex MACs with ballot masks) and subtracts / adds.  Nothing in the
+//    row loop depends on the next row, so the three-row prefetch distance holds.
 //  * Rows are processed in passes of 4 so that 6 channels x 4 accumulators fit
 //    in registers next to B (6 x 8 complex); after each pass the 64 lanes of a
-//    wave are summed through an LDS transpose (fixed order: deterministic).
+//    wave are summed through an LDS transpose (b128 stores, fixed order:
+//    deterministic).  The kernel is bound by VALU issue, not by HBM: the 96 packed
+//    FMAs per wave-row are 60 % of its instruction stream.
 //
 // Output: partial[job][0] = head (lo part of row 0, joins the carry from the
 // previous block), partial[job][q+1] = window q (q = 0..NC-2), partial[job][NC]
@@ -41,7 +46,8 @@ constexpr int kPassRows = 4;       // rows per accumulation pass
 constexpr int kStreamThreads = 256;
 constexpr int kJ = 8;              // code positions per lane
 constexpr int kTrVals = 2 * kGroupCh * kPassRows;            // 48 floats per lane and pass
-constexpr int kTrStride = kTrVals + 1;                       // + pad: conflict-free both ways
+constexpr int kTrCols = kTrVals + 2 * kGroupCh;              // + the six carry sums into the previous row
+constexpr int kTrStride = 68;                                // floats per lane: 16-byte rows, conflict-free
 
 struct StreamChan {
     float om, ph;
@@ -61,16 +67,36 @@ __device__ __forceinline__ void cmac(float2& a, float2 b, float2 x) {
 // v_pk_fma_f32 on (re, im) register pairs: op_sel picks the halves, neg_lo
 // supplies the minus sign of re -= b.im*x.im, so b stays one register pair
 // (hipcc's own packing keeps (b.re, b.re) and (-b.im, b.im) copies: 4 VGPRs per
-// element).  The two chains are interleaved and the block ends in s_nop, which
-// covers the one wait state gfx950 needs between a packed write and its reader.
+// element).  Dependent packed FMAs need no wait state on gfx950 (checked with
+// tools/probe/hazard_probe.hip); the two chains are interleaved anyway.
 __device__ __forceinline__ void cmac2(v2f& a0, v2f& a1, v2f b0, v2f x0, v2f b1, v2f x1) {
     asm("v_pk_fma_f32 %0, %2, %3, %0 op_sel_hi:[0,1,1]\n\t"
         "v_pk_fma_f32 %1, %4, %5, %1 op_sel_hi:[0,1,1]\n\t"
         "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"
-        "v_pk_fma_f32 %1, %4, %5, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"
-        "s_nop 0"
+        "v_pk_fma_f32 %1, %4, %5, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
         : "+v"(a0), "+v"(a1)
         : "v"(b0), "v"(x0), "v"(b1), "v"(x1));
+}
+
+// One sample against six channels: a[c] += b[c] * x, twelve packed FMAs with the two
+// updates of an accumulator six instructions apart (4.9 cycles per instruction
+// measured, 126 TFLOP/s chip-wide).
+__device__ __forceinline__ void cmac6(v2f& a0, v2f& a1, v2f& a2, v2f& a3, v2f& a4, v2f& a5, v2f b0,
+                                      v2f b1, v2f b2, v2f b3, v2f b4, v2f b5, v2f x) {
+    asm("v_pk_fma_f32 %0, %6, %12, %0 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %1, %7, %12, %1 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %2, %8, %12, %2 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %3, %9, %12, %3 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %4, %10, %12, %4 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %5, %11, %12, %5 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %0, %6, %12, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"
+        "v_pk_fma_f32 %1, %7, %12, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"
+        "v_pk_fma_f32 %2, %8, %12, %2 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"
+        "v_pk_fma_f32 %3, %9, %12, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"
+        "v_pk_fma_f32 %4, %10, %12, %4 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"
+        "v_pk_fma_f32 %5, %11, %12, %5 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5)
+        : "v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(b4), "v"(b5), "v"(x));
 }
 
 // (cos, -sin) of 2*pi*rev, i.e. exp(-j 2 pi rev), |error| ~ 1e-7.  Exact range
@@ -105,19 +131,33 @@ __device__ __forceinline__ v2f mask_pair(v2f x, unsigned long long m) {
     return d;
 }
 
-// Correction of the one mixed wave of a channel for one row: its lo elements
-// belong to the window of the row above, i.e. they must see x[r+1] instead of
-// x[r]; the plain pass already added B*x[r], so add B*(x[r+1]-x[r]) for them.
-// Chunks (128 positions, two elements per lane) below the boundary chunk IS are
-// lo in every lane; chunk IS is lo where the ballot masks say so.
+// Sum over the shorter side of the delay boundary of one row, for the one mixed wave
+// of a channel.  V = 0: chunk 0 masked; V = 1: chunk 0 whole + chunk 1 masked (the lo
+// side, boundary in chunk 0 or 1); V = 2: chunk 2 masked + chunk 3 whole; V = 3:
+// chunk 3 masked (the hi side, boundary in chunk 2 or 3).  A chunk is 128 positions,
+// two elements per lane; the ballot masks select the lanes of the boundary chunk
+// that are on that side.
+template <int V>
+__device__ __forceinline__ v2f side_sum(const v2f* B, const v2f* x, unsigned long long m0,
+                                        unsigned long long m1) {
+    constexpr int IS = V;                                      // the boundary chunk
+    v2f t0 = v2f{0.f, 0.f}, t1 = v2f{0.f, 0.f};
+    if (V == 1) cmac2(t0, t1, B[0], x[0], B[1], x[1]);
+    if (V == 2) cmac2(t0, t1, B[6], x[6], B[7], x[7]);
+    cmac2(t0, t1, B[2 * IS], mask_pair(x[2 * IS], m0), B[2 * IS + 1], mask_pair(x[2 * IS + 1], m1));
+    return t0 + t1;
+}
+
+// (kept for the LDS-ring variant) sum of the lo elements: chunks below IS whole,
+// chunk IS where the masks say so
 template <int IS>
-__device__ __forceinline__ void mixed_fix(v2f& acc, const v2f* B, const v2f* df,
-                                          unsigned long long m0, unsigned long long m1) {
+__device__ __forceinline__ v2f lo_sum(const v2f* B, const v2f* x, unsigned long long m0,
+                                      unsigned long long m1) {
     v2f t0 = v2f{0.f, 0.f}, t1 = v2f{0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < IS; ++i) cmac2(t0, t1, B[2 * i], df[2 * i], B[2 * i + 1], df[2 * i + 1]);
-    cmac2(t0, t1, B[2 * IS], mask_pair(df[2 * IS], m0), B[2 * IS + 1], mask_pair(df[2 * IS + 1], m1));
-    acc += t0 + t1;
+    for (int i = 0; i < IS; ++i) cmac2(t0, t1, B[2 * i], x[2 * i], B[2 * i + 1], x[2 * i + 1]);
+    cmac2(t0, t1, B[2 * IS], mask_pair(x[2 * IS], m0), B[2 * IS + 1], mask_pair(x[2 * IS + 1], m1));
+    return t0 + t1;
 }
 
 // GEN = false: code period of exactly 2048 samples (one chunk, the hot path).
@@ -131,10 +171,10 @@ __global__ __launch_bounds__(kStreamThreads, 2) void trk_stream_kernel(
     const JobMid* __restrict__ mid, const float* __restrict__ code, TrkParams P,
     int ngroups, int nblocks, float2* __restrict__ partial) {
     static_assert(NC % kPassRows == 0 && kPassRows == 4, "the row ring assumes passes of four rows");
-    __shared__ float tr[4][64][kTrStride];                    // per-wave transpose scratch
+    __shared__ __attribute__((aligned(16))) float tr[4][64][kTrStride];   // per-wave transpose scratch
     __shared__ float2 sw[4][kGroupCh][NC];                    // per-wave row sums
     __shared__ int cls[4][kGroupCh];                          // 0 hi, 1 lo, 2 mixed
-    __shared__ float2 hd[4][kGroupCh];                        // head sums of the mixed waves
+    __shared__ float2 hd[4][kGroupCh];                        // mixed quarters: lo part of row 0 (head)
     __shared__ StreamChan schan[kGroupCh];
     __shared__ float2 rot[kGroupCh][kJ + 1];                  // exp(-j w off_j/fs), [kJ]: exp(-j w T)
 
@@ -172,7 +212,10 @@ __global__ __launch_bounds__(kStreamThreads, 2) void trk_stream_kernel(
     v2f B[kGroupCh][kJ];
     int kcls[kGroupCh], istar[kGroupCh];
     unsigned long long lm0[kGroupCh], lm1[kGroupCh];
-    const int mbase = 2048 * chunk + 512 * wave + 2 * lane;   // m = mbase + 128 i + e
+    // the quarter of the code period a wave owns rotates with the block, so that a
+    // wave slot (= SIMD) does not get the delay boundaries of every block
+    const int wq = (wave + b) & 3;
+    const int mbase = 2048 * chunk + 512 * wq + 2 * lane;     // m = mbase + 128 i + e
     int xo[4];                                                // GEN: load offsets in the row
 #pragma unroll
     for (int i = 0; i < 4; ++i) xo[i] = (mbase + 128 * i < cs) ? mbase + 128 * i : 0;
@@ -191,12 +234,12 @@ __global__ __launch_bounds__(kStreamThreads, 2) void trk_stream_kernel(
         float2 z0 = phasor_rev(rev0);
         const float2 rT = rot[c][kJ];
         // wave-uniform class: 0 all hi (m >= d), 1 all lo, 2 mixed
-        const int w0 = 2048 * chunk + 512 * wave;
+        const int w0 = 2048 * chunk + 512 * wq;
         int k = (s.d <= w0) ? 0 : (s.d >= w0 + 512 ? 1 : 2);
         if (!s.active) k = 0;
         k = __builtin_amdgcn_readfirstlane(k);
         kcls[c] = k;
-        if (lane == 0) cls[wave][c] = k;
+        if (lane == 0) cls[wq][c] = k;
         if (k == 1) z0 = cmulf(z0, rT);                       // every element is lo
         const float* cv = code + (size_t)s.prn * cs;
 #pragma unroll
@@ -218,114 +261,95 @@ __global__ __launch_bounds__(kStreamThreads, 2) void trk_stream_kernel(
             }
             B[c][j] = v2f{v * z.x, v * z.y};
         }
-        // mixed wave: boundary chunk and the lane masks of its two elements
+        // mixed wave: boundary chunk and the lane masks of its two elements, for the
+        // shorter side of the boundary (lo if it lies in chunk 0 or 1, else hi)
         int is = 0;
         unsigned long long b0 = 0, b1 = 0;
         if (k == 2) {
-            is = (s.d - w0 - 1) >> 7;                          // chunk holding m = d-1
-            b0 = __ballot(w0 + 128 * is + 2 * lane < s.d);
-            b1 = __ballot(w0 + 128 * is + 2 * lane + 1 < s.d);
+            is = __builtin_amdgcn_readfirstlane((s.d - w0 - 1) >> 7);   // chunk holding m = d-1
+            const bool hi_side = is >= 2;                      // which side side_sum<> adds up
+            b0 = __ballot((w0 + 128 * is + 2 * lane < s.d) != hi_side);
+            b1 = __ballot((w0 + 128 * is + 2 * lane + 1 < s.d) != hi_side);
         }
         istar[c] = __builtin_amdgcn_readfirstlane(is);
         lm0[c] = b0;
         lm1[c] = b1;
     }
-    int anymixed = 0;
-#pragma unroll
-    for (int c = 0; c < kGroupCh; ++c) anymixed |= (kcls[c] == 2);
-
     // ---- stream the rows
     // ring of four row buffers with static roles: row r lives in xb[r & 3]; while
     // row r is processed, row r+3 is loaded into the buffer row r-1 just left
     // (prefetch distance three rows, no register copies)
     v2f xb[4][kJ];
+    // Loads are unconditional (rows past the end re-read the last row; their data is
+    // never used): a load inside a branch gives the paths different numbers of
+    // outstanding loads and hipcc then falls back to s_waitcnt vmcnt(0).
     auto load_row = [&](v2f* dst, int r) {
-        if (r < NC) {
-            const float2* row = blk + (size_t)r * cs;
-            const float4* p = reinterpret_cast<const float4*>(row + mbase);
+        const float2* row = blk + (size_t)(r < NC ? r : NC - 1) * cs;
+        const float4* p = reinterpret_cast<const float4*>(row + mbase);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float4 v;
-                if (GEN) v = *reinterpret_cast<const float4*>(row + xo[i]);
-                else v = p[i * 64];                            // 128 samples = 64 float4 apart
-                dst[2 * i] = v2f{v.x, v.y};
-                dst[2 * i + 1] = v2f{v.z, v.w};
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < kJ; ++j) dst[j] = v2f{0.f, 0.f};
+        for (int i = 0; i < 4; ++i) {
+            float4 v;
+            if (GEN) v = *reinterpret_cast<const float4*>(row + xo[i]);
+            else v = p[i * 64];                                // 128 samples = 64 float4 apart
+            dst[2 * i] = v2f{v.x, v.y};
+            dst[2 * i + 1] = v2f{v.z, v.w};
         }
+        __builtin_amdgcn_sched_barrier(0);                     // keep the loads up here
     };
     load_row(xb[0], 0);
     load_row(xb[1], 1);
     load_row(xb[2], 2);
 
-    // head: the lo part of row 0 belongs to window -1.  Pure lo waves get it by
-    // relabelling their row 0; the mixed wave adds it here.
-#pragma unroll
-    for (int c = 0; c < kGroupCh; ++c) {
-        v2f h = v2f{0.f, 0.f};
-        if (kcls[c] == 2) {
-            switch (istar[c]) {
-                case 0: mixed_fix<0>(h, B[c], xb[0], lm0[c], lm1[c]); break;
-                case 1: mixed_fix<1>(h, B[c], xb[0], lm0[c], lm1[c]); break;
-                case 2: mixed_fix<2>(h, B[c], xb[0], lm0[c], lm1[c]); break;
-                default: mixed_fix<3>(h, B[c], xb[0], lm0[c], lm1[c]); break;
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                h.x += __shfl_down(h.x, o, 64);
-                h.y += __shfl_down(h.y, o, 64);
-            }
-        }
-        if (lane == 0) hd[wave][c] = make_float2(h.x, h.y);
-    }
-
 #pragma unroll 1
     for (int pass = 0; pass < NC / kPassRows; ++pass) {
         v2f acc[kGroupCh][kPassRows];
+        v2f carry[kGroupCh];                // lo part of the pass's first row: belongs to the row above
 #pragma unroll
-        for (int c = 0; c < kGroupCh; ++c)
+        for (int c = 0; c < kGroupCh; ++c) {
+            carry[c] = v2f{0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < kPassRows; ++r) acc[c][r] = v2f{0.f, 0.f};
+        }
 #pragma unroll
         for (int rr = 0; rr < kPassRows; ++rr) {
             const int r = pass * kPassRows + rr;
             v2f* xc = xb[rr & 3];
-            v2f* xn = xb[(rr + 1) & 3];
             load_row(xb[(rr + 3) & 3], r + 3);
             // every channel, every element: acc[row] += B * x[row]
             if (!(P.flags & 1)) {
 #pragma unroll
                 for (int j = 0; j < kJ; ++j)
-#pragma unroll
-                    for (int c = 0; c < kGroupCh; c += 2)
-                        cmac2(acc[c][rr], acc[c + 1][rr], B[c][j], xc[j], B[c + 1][j], xc[j]);
+                    cmac6(acc[0][rr], acc[1][rr], acc[2][rr], acc[3][rr], acc[4][rr], acc[5][rr],
+                          B[0][j], B[1][j], B[2][j], B[3][j], B[4][j], B[5][j], xc[j]);
             } else {
 #pragma unroll
                 for (int j = 0; j < kJ; ++j) asm volatile("" ::"v"(xc[j]));
                 acc[0][rr] += xc[0];
             }
-            // the one mixed wave of a channel: its lo elements take row r+1 instead
-            if (anymixed && !(P.flags & 4)) {
-                v2f df[kJ];
-#pragma unroll
-                for (int j = 0; j < kJ; ++j) df[j] = xn[j] - xc[j];
+            // the one mixed wave of a channel: the lo elements of the row belong to the
+            // window of the row above
+            if (!(P.flags & 4)) {
 #pragma unroll
                 for (int c = 0; c < kGroupCh; ++c) {
                     if (kcls[c] == 2) {
+                        v2f sd;
                         switch (istar[c]) {
-                            case 0: mixed_fix<0>(acc[c][rr], B[c], df, lm0[c], lm1[c]); break;
-                            case 1: mixed_fix<1>(acc[c][rr], B[c], df, lm0[c], lm1[c]); break;
-                            case 2: mixed_fix<2>(acc[c][rr], B[c], df, lm0[c], lm1[c]); break;
-                            default: mixed_fix<3>(acc[c][rr], B[c], df, lm0[c], lm1[c]); break;
+                            case 0: sd = side_sum<0>(B[c], xc, lm0[c], lm1[c]); break;
+                            case 1: sd = side_sum<1>(B[c], xc, lm0[c], lm1[c]); break;
+                            case 2: sd = side_sum<2>(B[c], xc, lm0[c], lm1[c]); break;
+                            default: sd = side_sum<3>(B[c], xc, lm0[c], lm1[c]); break;
                         }
+                        // lo side summed: lo = sd; hi side summed: lo = total - sd
+                        const v2f lo = istar[c] < 2 ? sd : acc[c][rr] - sd;
+                        acc[c][rr] -= lo;
+                        if (rr == 0) carry[c] += lo;
+                        else acc[c][rr - 1] += lo;
                     }
                 }
             }
         }
         // ---- sum over the 64 lanes of the wave: transpose through LDS
-        // (6 channels x 4 rows x re/im = 48 values per lane), fixed order
+        // (6 channels x 4 rows x re/im = 48 values per lane + 12 carries), fixed order
         if (P.flags & 2) {
             if (lane < kTrVals) {
                 const int c = lane / (2 * kPassRows), rr = (lane % (2 * kPassRows)) / 2;
@@ -334,7 +358,7 @@ __global__ __launch_bounds__(kStreamThreads, 2) void trk_stream_kernel(
                 for (int cc = 0; cc < kGroupCh; ++cc)
 #pragma unroll
                     for (int r2 = 0; r2 < kPassRows; ++r2) sacc += acc[cc][r2].x + acc[cc][r2].y;
-                reinterpret_cast<float*>(&sw[wave][c][pass * kPassRows + rr])[lane & 1] = sacc;
+                reinterpret_cast<float*>(&sw[wq][c][pass * kPassRows + rr])[lane & 1] = sacc;
             }
             continue;
         }
@@ -343,24 +367,42 @@ __global__ __launch_bounds__(kStreamThreads, 2) void trk_stream_kernel(
         // is wanted: __syncthreads() would also wait for vmcnt(0) and drain the
         // three rows of loads in flight.
         __builtin_amdgcn_wave_barrier();
+        {
+            float4* row4 = reinterpret_cast<float4*>(&tr[wave][lane][0]);
 #pragma unroll
-        for (int v = 0; v < kTrVals; ++v) {
-            const int c = v / (2 * kPassRows), rr = (v % (2 * kPassRows)) / 2;
-            tr[wave][lane][v] = (v & 1) ? acc[c][rr].y : acc[c][rr].x;
+            for (int c = 0; c < kGroupCh; ++c) {
+                row4[2 * c] = make_float4(acc[c][0].x, acc[c][0].y, acc[c][1].x, acc[c][1].y);
+                row4[2 * c + 1] = make_float4(acc[c][2].x, acc[c][2].y, acc[c][3].x, acc[c][3].y);
+            }
+#pragma unroll
+            for (int c = 0; c < kGroupCh; c += 2)
+                row4[2 * kGroupCh + c / 2] =
+                    make_float4(carry[c].x, carry[c].y, carry[c + 1].x, carry[c + 1].y);
         }
         __builtin_amdgcn_wave_barrier();
-        if (lane < kTrVals) {
-            float s = 0.f;
+        if (lane < kTrCols) {
+            v2f s2 = v2f{0.f, 0.f};
 #pragma unroll 8
-            for (int l = 0; l < 64; ++l) s += tr[wave][l][lane];
-            const int c = lane / (2 * kPassRows), rr = (lane % (2 * kPassRows)) / 2;
-            float* dst = reinterpret_cast<float*>(&sw[wave][c][pass * kPassRows + rr]);
-            dst[lane & 1] = s;
+            for (int l = 0; l < 64; l += 2) s2 += v2f{tr[wave][l][lane], tr[wave][l + 1][lane]};
+            const float s = s2.x + s2.y;
+            if (lane < kTrVals) {
+                const int c = lane / (2 * kPassRows), rr = (lane % (2 * kPassRows)) / 2;
+                float* dst = reinterpret_cast<float*>(&sw[wq][c][pass * kPassRows + rr]);
+                dst[lane & 1] = s;
+            } else {                        // carries: into the last row of the pass before
+                const int c = (lane - kTrVals) >> 1;
+                float* dst = pass == 0 ? reinterpret_cast<float*>(&hd[wq][c])
+                                       : reinterpret_cast<float*>(&sw[wq][c][pass * kPassRows - 1]);
+                if (pass == 0) dst[lane & 1] = s;
+                else dst[lane & 1] += s;
+            }
         }
+        if (P.flags & 16) __builtin_amdgcn_s_barrier();       // experiment: couple the waves
     }
     __syncthreads();
 
-    // ---- combine the four waves (fixed order), apply U, write the partial sums
+    // ---- combine the four quarters (fixed order, whichever wave summed them), apply U,
+    // write the partial sums
     // out index o = q + 1, q = -1 .. NC-1.  A lo wave's row r is window r-1.
     for (int item = t; item < kGroupCh * (NC + 1); item += kStreamThreads) {
         const int c = item / (NC + 1), o = item % (NC + 1), q = o - 1;

@@ -33,6 +33,15 @@ namespace gpsmi {
 constexpr int kRing = 8;                 // row slots in LDS
 constexpr int kDepth = kRing - 1;        // rows in flight
 
+// Correction of the one mixed wave of a channel for one row (this variant keeps the
+// x[r+1]-x[r] form): its lo elements must see x[r+1] instead of x[r]; the plain pass
+// already added B*x[r], so add B*(x[r+1]-x[r]) for them.
+template <int IS>
+__device__ __forceinline__ void mixed_fix(v2f& acc, const v2f* B, const v2f* df,
+                                          unsigned long long m0, unsigned long long m1) {
+    acc += lo_sum<IS>(B, df, m0, m1);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

@@ -18,6 +18,8 @@ ap.add_argument('--channels', type=int, default=12)
 ap.add_argument('--iters', type=int, default=20)
 ap.add_argument('--code-samples', type=int, default=2048)
 ap.add_argument('--n-cyc', type=int, default=32)
+ap.add_argument('--delays', default='spread',
+                help='spread | aligned (multiples of 512: no mixed wave) | balanced | onewave')
 a = ap.parse_args()
 
 CS = a.code_samples
@@ -30,8 +32,18 @@ chunk = (rng.standard_normal((16, NGPS, 2)) * 0.25).astype(np.float32)
 for i in range(0, nb, 16):
     n = min(16, nb - i)
     buf.upload(chunk[:n], i * NGPS * 8)
+def delay_of(c):
+    if a.delays == 'aligned':
+        return (512 * c) % CS
+    if a.delays == 'balanced':          # 2,2,1,1 mixed channels per wave in each group of six
+        return [100, 300, 700, 900, 1200, 1800][c % 6] % CS
+    if a.delays == 'onewave':
+        return (40 * (c % 6) + 20) % CS
+    return (1137 * c + 11) % CS
+
+
 for c in range(nch):
-    trk.open(c, 2 + c, -4000.0 + 700.0 * c, (1137 * c + 11) % CS)
+    trk.open(c, 2 + c, -4000.0 + 700.0 * c, delay_of(c))
 st = np.zeros((nb, nch), dtype=E.STATE_DTYPE)
 for c in range(nch):
     st[:, c] = trk.get_state(c)
@@ -46,6 +58,6 @@ for i in range(a.iters + 3):
         tot.append(t)
         cor.append(c)
 gb = nb * NGPS * 8 / 1e9
-print(f'cs {CS} n_cyc {a.n_cyc} blocks {nb} channels {nch}: correlator {np.median(cor):.4f} ms '
+print(f'delays {a.delays} cs {CS} n_cyc {a.n_cyc} blocks {nb} channels {nch}: correlator {np.median(cor):.4f} ms '
       f'({gb / np.median(cor) * 1e3:.0f} GB/s, min {min(cor):.4f}), '
       f'all tracking kernels {np.median(tot):.4f} ms')
