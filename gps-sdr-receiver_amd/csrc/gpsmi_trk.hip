@@ -53,7 +53,8 @@ struct TrkParams {
     int df_no;         // 1024 / n_cyc
     float t_last;      // SEC_TIME[NGPS-1]
     float om_min, om_max;   // float32(2*pi*MIN_FREQ), float32(2*pi*MAX_FREQ) from float64
-    int flags;              // diagnostics only (GPSMI_DEBUG_FLAGS): 1 no MAC, 2 no lane sums, 4 no mixed fix, 8 LDS-ring correlator
+    int flags;              // diagnostics only (GPSMI_DEBUG_FLAGS): 1 no MAC, 2 no lane sums, 4 no mixed fix,
+                            // 8 LDS-ring correlator
 };
 
 // per-job descriptor handed from the correlation kernel to the correlator and
@@ -308,7 +309,8 @@ struct gpsmi_trk {
     int corr_cg = 6;
     // code_samples != 2048: time-domain correlation + chunked correlator
     bool general = false;
-    int nchunks = 1;
+    int stream_j = 8;                // code positions per lane of the correlator (8 or 4)
+    int nchunks = 1;                 // spans of 256 * stream_j positions per code period
     float2* d_fold = nullptr; float* d_mag = nullptr; DirStats* d_stats = nullptr;
     int* d_xsel = nullptr; int* d_rsel = nullptr; float2* d_partial_g = nullptr;
     TrkParams P;
@@ -331,9 +333,10 @@ static int trk_reserve(gpsmi_trk* h, size_t njobs) {
         GPSMI_HIP(hipMalloc((void**)&h->d_stats, njobs * sizeof(DirStats)));
         GPSMI_HIP(hipMalloc((void**)&h->d_xsel, njobs * sizeof(int)));
         GPSMI_HIP(hipMalloc((void**)&h->d_rsel, njobs * sizeof(int)));
+    }
+    if (h->nchunks > 1)
         GPSMI_HIP(hipMalloc((void**)&h->d_partial_g,
                             njobs * h->nchunks * (h->cfg.n_cyc + 1) * sizeof(float2)));
-    }
     GPSMI_HIP(hipMalloc((void**)&h->d_tab_in, njobs * sizeof(gpsmi_trk_state)));
     GPSMI_HIP(hipMalloc((void**)&h->d_tab_out, njobs * sizeof(gpsmi_trk_state)));
     GPSMI_HIP(hipMalloc((void**)&h->d_forced, njobs * sizeof(int)));
@@ -355,6 +358,7 @@ static int trk_launch(gpsmi_trk* h, const float2* d_iq, const gpsmi_trk_state* s
     const int nblocks = njobs / nch;
     const int ngroups = (nch + kGroupCh - 1) / kGroupCh;
     const dim3 sgrid(((nblocks + 7) / 8) * 8 * ngroups);
+    // ---- code-phase correlation
     if (h->general) {
         const int cs = P.cs;
         hipLaunchKernelGGL(trk_fold_general_kernel, dim3((cs + 255) / 256, njobs), dim3(256), 0,
@@ -367,34 +371,7 @@ static int trk_launch(gpsmi_trk* h, const float2* d_iq, const gpsmi_trk_state* s
                            h->d_stats);
         hipLaunchKernelGGL(trk_decide_kernel, dim3((njobs + 255) / 256), dim3(256), 0, h->stream,
                            h->d_stats, forced, P, njobs, h->d_out, h->d_mid);
-        GPSMI_HIP(hipEventRecord(h->ev[1], h->stream));
-        const dim3 grid(sgrid.x, h->nchunks), block(kStreamThreads);
-        switch (P.n_cyc) {
-            case 32:
-                hipLaunchKernelGGL((trk_stream_kernel<32, true>), grid, block, 0, h->stream, d_iq,
-                                   st_in, h->d_mid, h->d_code, P, ngroups, nblocks, h->d_partial_g);
-                break;
-            case 16:
-                hipLaunchKernelGGL((trk_stream_kernel<16, true>), grid, block, 0, h->stream, d_iq,
-                                   st_in, h->d_mid, h->d_code, P, ngroups, nblocks, h->d_partial_g);
-                break;
-            default:
-                hipLaunchKernelGGL((trk_stream_kernel<8, true>), grid, block, 0, h->stream, d_iq,
-                                   st_in, h->d_mid, h->d_code, P, ngroups, nblocks, h->d_partial_g);
-                break;
-        }
-        const int per_job = P.n_cyc + 1;
-        hipLaunchKernelGGL(trk_partial_reduce_kernel, dim3((njobs * per_job + 255) / 256), dim3(256),
-                           0, h->stream, h->d_partial_g, h->nchunks, per_job, njobs, h->d_mid,
-                           h->d_partial);
-        GPSMI_HIP(hipEventRecord(h->ev[2], h->stream));
-        hipLaunchKernelGGL(trk_epilogue_kernel, dim3((njobs + 3) / 4), dim3(256), 0, h->stream,
-                           st_in, st_out, h->d_mid, h->d_partial, P, njobs, h->d_out);
-        GPSMI_HIP(hipGetLastError());
-        GPSMI_HIP(hipEventRecord(h->ev[3], h->stream));
-        return GPSMI_OK;
-    }
-    {
+    } else {
         // channels per correlation workgroup: fewer channels = fewer live accumulators
         // = more workgroups per CU for the barrier-heavy FFT phase (GPSMI_CORR_CG to tune)
         const int cg = h->corr_cg;
@@ -411,21 +388,33 @@ static int trk_launch(gpsmi_trk* h, const float2* d_iq, const gpsmi_trk_state* s
                                h->d_rep, h->d_tw, P, ng, nblocks, h->d_out, h->d_mid);
     }
     GPSMI_HIP(hipEventRecord(h->ev[1], h->stream));
-    if (!(P.flags & 8)) {                  // default: the register-staged correlator
-        const dim3 grid = sgrid, block(kStreamThreads);
-        switch (P.n_cyc) {
-            case 32:
-                hipLaunchKernelGGL(trk_stream_kernel<32>, grid, block, 0, h->stream, d_iq, st_in,
-                                   h->d_mid, h->d_code, P, ngroups, nblocks, h->d_partial);
-                break;
-            case 16:
-                hipLaunchKernelGGL(trk_stream_kernel<16>, grid, block, 0, h->stream, d_iq, st_in,
-                                   h->d_mid, h->d_code, P, ngroups, nblocks, h->d_partial);
-                break;
-            default:
-                hipLaunchKernelGGL(trk_stream_kernel<8>, grid, block, 0, h->stream, d_iq, st_in,
-                                   h->d_mid, h->d_code, P, ngroups, nblocks, h->d_partial);
-                break;
+    // ---- the correlator
+    if (!(P.flags & 8) || h->general) {    // default: the register-staged correlator
+        const dim3 grid(sgrid.x, h->nchunks), block(kStreamThreads);
+        float2* pdst = h->nchunks > 1 ? h->d_partial_g : h->d_partial;
+#define GPSMI_LAUNCH_STREAM(NC, POW2, J)                                                        \
+    hipLaunchKernelGGL((trk_stream_kernel<NC, POW2, J>), grid, block, 0, h->stream, d_iq, st_in, \
+                       h->d_mid, h->d_code, P, ngroups, nblocks, pdst)
+#define GPSMI_LAUNCH_STREAM_NC(POW2, J)                 \
+    do {                                                \
+        if (P.n_cyc == 32) GPSMI_LAUNCH_STREAM(32, POW2, J);      \
+        else if (P.n_cyc == 16) GPSMI_LAUNCH_STREAM(16, POW2, J); \
+        else GPSMI_LAUNCH_STREAM(8, POW2, J);           \
+    } while (0)
+        if (h->general) {
+            if (h->stream_j == 8) GPSMI_LAUNCH_STREAM_NC(false, 8);
+            else GPSMI_LAUNCH_STREAM_NC(false, 4);
+        } else {
+            if (h->stream_j == 8) GPSMI_LAUNCH_STREAM_NC(true, 8);
+            else GPSMI_LAUNCH_STREAM_NC(true, 4);
+        }
+#undef GPSMI_LAUNCH_STREAM_NC
+#undef GPSMI_LAUNCH_STREAM
+        if (h->nchunks > 1) {
+            const int per_job = P.n_cyc + 1;
+            hipLaunchKernelGGL(trk_partial_reduce_kernel, dim3((njobs * per_job + 255) / 256),
+                               dim3(256), 0, h->stream, h->d_partial_g, h->nchunks, per_job, njobs,
+                               h->d_mid, h->d_partial);
         }
     } else {                               // GPSMI_DEBUG_FLAGS=8: the LDS-ring variant
 #define GPSMI_LAUNCH_LDS(NC, G)                                                                 \
@@ -488,7 +477,11 @@ int gpsmi_trk_create(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk** out) {
     h->cfg = *cfg;
     h->max_ch = max_ch;
     h->general = cfg->code_samples != kFftN;
-    h->nchunks = (cfg->code_samples + kFftN - 1) / kFftN;
+    {
+        const char* js = getenv("GPSMI_STREAM_J");
+        if (js && (atoi(js) == 4 || atoi(js) == 8)) h->stream_j = atoi(js);
+    }
+    h->nchunks = (cfg->code_samples + 256 * h->stream_j - 1) / (256 * h->stream_j);
     *out = h;
     GPSMI_HIP(hipStreamCreate(&h->stream));
     for (auto& e : h->ev) GPSMI_HIP(hipEventCreate(&e));

@@ -44,10 +44,12 @@ namespace gpsmi {
 constexpr int kGroupCh = 6;        // channels per workgroup
 constexpr int kPassRows = 4;       // rows per accumulation pass
 constexpr int kStreamThreads = 256;
-constexpr int kJ = 8;              // code positions per lane
+constexpr int kJ = 8;              // code positions per lane (LDS-ring variant; the default kernel takes J)
 constexpr int kTrVals = 2 * kGroupCh * kPassRows;            // 48 floats per lane and pass
 constexpr int kTrCols = kTrVals + 2 * kGroupCh;              // + the six carry sums into the previous row
-constexpr int kTrStride = 68;                                // floats per lane: 16-byte rows, conflict-free
+// transpose scratch: J = 8 (2 workgroups per CU) sums all 60 columns in one round,
+// J = 4 (3 per CU) in two rounds of 32; row strides of 68 / 36 floats keep the b128
+// stores and the b32 column reads free of bank conflicts
 
 struct StreamChan {
     float om, ph;
@@ -132,21 +134,24 @@ __device__ __forceinline__ v2f mask_pair(v2f x, unsigned long long m) {
 }
 
 // Sum over the shorter side of the delay boundary of one row, for the one mixed wave
-// of a channel.  V = 0: chunk 0 masked; V = 1: chunk 0 whole + chunk 1 masked (the lo
-// side, boundary in chunk 0 or 1); V = 2: chunk 2 masked + chunk 3 whole; V = 3:
-// chunk 3 masked (the hi side, boundary in chunk 2 or 3).  A chunk is 128 positions,
-// two elements per lane; the ballot masks select the lanes of the boundary chunk
-// that are on that side.
-template <int V>
+// of a channel.  A wave owns J/2 chunks of 128 positions (two elements per lane and
+// chunk); IS is the chunk holding the boundary.  Boundary in the lower half of the
+// chunks: the lo side is summed (chunks below IS whole, chunk IS where the ballot
+// masks say so); in the upper half: the hi side (chunk IS masked, chunks above whole).
+template <int J, int IS>
 __device__ __forceinline__ v2f side_sum(const v2f* B, const v2f* x, unsigned long long m0,
                                         unsigned long long m1) {
-    constexpr int IS = V;                                      // the boundary chunk
+    constexpr int NCH = J / 2;
+    constexpr bool HI = IS >= (NCH + 1) / 2;
     v2f t0 = v2f{0.f, 0.f}, t1 = v2f{0.f, 0.f};
-    if (V == 1) cmac2(t0, t1, B[0], x[0], B[1], x[1]);
-    if (V == 2) cmac2(t0, t1, B[6], x[6], B[7], x[7]);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+        if (HI ? i > IS : i < IS) cmac2(t0, t1, B[2 * i], x[2 * i], B[2 * i + 1], x[2 * i + 1]);
     cmac2(t0, t1, B[2 * IS], mask_pair(x[2 * IS], m0), B[2 * IS + 1], mask_pair(x[2 * IS + 1], m1));
     return t0 + t1;
 }
+template <int J>
+__device__ __forceinline__ bool side_is_hi(int is) { return is >= (J / 2 + 1) / 2; }
 
 // (kept for the LDS-ring variant) sum of the lo elements: chunks below IS whole,
 // chunk IS where the masks say so
@@ -160,23 +165,30 @@ __device__ __forceinline__ v2f lo_sum(const v2f* B, const v2f* x, unsigned long 
     return t0 + t1;
 }
 
-// GEN = false: code period of exactly 2048 samples (one chunk, the hot path).
-// GEN = true: any code length that is a multiple of 16; blockIdx.y selects a chunk
-// of 2048 positions of the code period, positions beyond CS are masked (B = 0,
-// their loads redirected to position 0 of the row) and each chunk writes its own
-// partial sums (partial[job][chunk][NC+1], added up by trk_partial_reduce_kernel).
-template <int NC, bool GEN = false>
-__global__ __launch_bounds__(kStreamThreads, 2) void trk_stream_kernel(
+// J = code positions per lane (8 or 4).  A workgroup of 256 threads covers a span of
+// 256 J positions of the code period: with J = 8 and CS = 2048 the whole period, else
+// blockIdx.y selects the span ("chunk"), positions beyond CS are masked (B = 0, their
+// loads redirected to position 0 of the row) and each span writes its own partial
+// sums (partial[job][span][NC+1], added up by trk_partial_reduce_kernel).  J = 4
+// halves B and the row ring: 3 workgroups per CU instead of 2.
+// POW2: CS is 2048 (replica index by mask); otherwise any multiple of 16.
+template <int NC, bool POW2, int J>
+__global__ __launch_bounds__(kStreamThreads, J == 8 ? 2 : 3) void trk_stream_kernel(
     const float2* __restrict__ iq, const gpsmi_trk_state* __restrict__ st_in,
     const JobMid* __restrict__ mid, const float* __restrict__ code, TrkParams P,
     int ngroups, int nblocks, float2* __restrict__ partial) {
     static_assert(NC % kPassRows == 0 && kPassRows == 4, "the row ring assumes passes of four rows");
+    static_assert(J == 8 || J == 4, "positions per lane");
+    constexpr int kSpan = kStreamThreads * J;                 // positions per workgroup
+    constexpr int kWaveSpan = 64 * J;                         // positions per wave
+    constexpr int NLD = J / 2;                                // float4 loads per lane and row
+    constexpr int kRounds = J == 8 ? 1 : 2, kTrHalf = 64 / kRounds, kTrStride = J == 8 ? 68 : 36;
     __shared__ __attribute__((aligned(16))) float tr[4][64][kTrStride];   // per-wave transpose scratch
-    __shared__ float2 sw[4][kGroupCh][NC];                    // per-wave row sums
+    __shared__ float2 sw[4][kGroupCh][NC];                    // per-quarter row sums
     __shared__ int cls[4][kGroupCh];                          // 0 hi, 1 lo, 2 mixed
     __shared__ float2 hd[4][kGroupCh];                        // mixed quarters: lo part of row 0 (head)
     __shared__ StreamChan schan[kGroupCh];
-    __shared__ float2 rot[kGroupCh][kJ + 1];                  // exp(-j w off_j/fs), [kJ]: exp(-j w T)
+    __shared__ float2 rot[kGroupCh][J + 1];                   // exp(-j w off_j/fs), [J]: exp(-j w T)
 
     // XCD-aware decode: the groups of one block run on one XCD, back to back
     const int wg = blockIdx.x;
@@ -186,39 +198,40 @@ __global__ __launch_bounds__(kStreamThreads, 2) void trk_stream_kernel(
     if (b >= nblocks) return;
 
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    const int cs = GEN ? P.cs : kFftN;
-    const int chunk = GEN ? (int)blockIdx.y : 0, nchunks = GEN ? (int)gridDim.y : 1;
+    const int cs = POW2 ? kFftN : P.cs;
+    const int chunk = blockIdx.y, nchunks = gridDim.y;
     const float2* blk = iq + (size_t)b * ((size_t)cs * NC);
     const float inv_fs = 1.0f / (1000.0f * (float)cs);
 
     // ---- per-channel set-up
     // (a) wave-uniform rotation constants, one thread each, angles in double
     const double inv_2pi = 0.15915494309189533576888376337251;
-    if (t < kGroupCh * (kJ + 1)) {
-        const int c = t / (kJ + 1), k = t % (kJ + 1);
+    if (t < kGroupCh * (J + 1)) {
+        const int c = t / (J + 1), k = t % (J + 1);
         const int cidx = g * kGroupCh + c;
         float2 r = make_float2(1.f, 0.f);
         const JobMid md = mid[b * P.nch + (cidx < P.nch ? cidx : P.nch - 1)];
         if (cidx < P.nch && md.active) {
-            const int off = (k == kJ) ? cs : 128 * (k >> 1) + (k & 1);
+            const int off = (k == J) ? cs : 128 * (k >> 1) + (k & 1);
             const double rev = (double)md.om * inv_2pi * (double)off / (1000.0 * (double)cs);
             r = phasor_rev((float)(rev - rint(rev)));
         }
         rot[c][k] = r;
     }
     __syncthreads();
-    // (b) B in registers: one base phasor per channel and lane, the other seven
-    // positions by rotation; lo elements carry one extra row rotation
-    v2f B[kGroupCh][kJ];
+    // (b) B in registers: one base phasor per channel and lane, the other positions by
+    // rotation; lo elements carry one extra row rotation
+    v2f B[kGroupCh][J];
     int kcls[kGroupCh], istar[kGroupCh];
     unsigned long long lm0[kGroupCh], lm1[kGroupCh];
-    // the quarter of the code period a wave owns rotates with the block, so that a
-    // wave slot (= SIMD) does not get the delay boundaries of every block
+    // the quarter of the span a wave owns rotates with the block, so that a wave slot
+    // (= SIMD) does not get the delay boundaries of every block
     const int wq = (wave + b) & 3;
-    const int mbase = 2048 * chunk + 512 * wq + 2 * lane;     // m = mbase + 128 i + e
-    int xo[4];                                                // GEN: load offsets in the row
+    const int w0 = kSpan * chunk + kWaveSpan * wq;            // first position of the wave
+    const int mbase = w0 + 2 * lane;                          // m = mbase + 128 i + e
+    int xo[NLD];                                              // load offsets in the row
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xo[i] = (mbase + 128 * i < cs) ? mbase + 128 * i : 0;
+    for (int i = 0; i < NLD; ++i) xo[i] = (mbase + 128 * i < cs) ? mbase + 128 * i : 0;
 #pragma unroll
     for (int c = 0; c < kGroupCh; ++c) {
         const int cidx = g * kGroupCh + c;
@@ -232,10 +245,9 @@ __global__ __launch_bounds__(kStreamThreads, 2) void trk_stream_kernel(
         const float f_eff = (float)((double)s.om * inv_2pi);
         const float rev0 = fmaf(f_eff, (float)(mbase + 1) * inv_fs, s.ph * (float)inv_2pi);
         float2 z0 = phasor_rev(rev0);
-        const float2 rT = rot[c][kJ];
+        const float2 rT = rot[c][J];
         // wave-uniform class: 0 all hi (m >= d), 1 all lo, 2 mixed
-        const int w0 = 2048 * chunk + 512 * wq;
-        int k = (s.d <= w0) ? 0 : (s.d >= w0 + 512 ? 1 : 2);
+        int k = (s.d <= w0) ? 0 : (s.d >= w0 + kWaveSpan ? 1 : 2);
         if (!s.active) k = 0;
         k = __builtin_amdgcn_readfirstlane(k);
         kcls[c] = k;
@@ -243,7 +255,7 @@ __global__ __launch_bounds__(kStreamThreads, 2) void trk_stream_kernel(
         if (k == 1) z0 = cmulf(z0, rT);                       // every element is lo
         const float* cv = code + (size_t)s.prn * cs;
 #pragma unroll
-        for (int j = 0; j < kJ; ++j) {
+        for (int j = 0; j < J; ++j) {
             const int m = mbase + 128 * (j >> 1) + (j & 1);
             float2 z = (j == 0) ? z0 : cmulf(z0, rot[c][j]);
             if (k == 2) {                                     // only the mixed wave decides per element
@@ -252,22 +264,22 @@ __global__ __launch_bounds__(kStreamThreads, 2) void trk_stream_kernel(
                 z = make_float2(lo ? zl.x : z.x, lo ? zl.y : z.y);
             }
             float v;
-            if (GEN) {
+            if (POW2) {
+                v = s.active ? cv[(m - s.d) & (cs - 1)] : 0.f;
+            } else {
                 int idx = m - s.d;
                 if (idx < 0) idx += cs;
                 v = (s.active && m < cs) ? cv[idx] : 0.f;
-            } else {
-                v = s.active ? cv[(m - s.d) & (cs - 1)] : 0.f;
             }
             B[c][j] = v2f{v * z.x, v * z.y};
         }
         // mixed wave: boundary chunk and the lane masks of its two elements, for the
-        // shorter side of the boundary (lo if it lies in chunk 0 or 1, else hi)
+        // shorter side of the boundary (see side_sum)
         int is = 0;
         unsigned long long b0 = 0, b1 = 0;
         if (k == 2) {
             is = __builtin_amdgcn_readfirstlane((s.d - w0 - 1) >> 7);   // chunk holding m = d-1
-            const bool hi_side = is >= 2;                      // which side side_sum<> adds up
+            const bool hi_side = side_is_hi<J>(is);
             b0 = __ballot((w0 + 128 * is + 2 * lane < s.d) != hi_side);
             b1 = __ballot((w0 + 128 * is + 2 * lane + 1 < s.d) != hi_side);
         }
@@ -279,7 +291,7 @@ __global__ __launch_bounds__(kStreamThreads, 2) void trk_stream_kernel(
     // ring of four row buffers with static roles: row r lives in xb[r & 3]; while
     // row r is processed, row r+3 is loaded into the buffer row r-1 just left
     // (prefetch distance three rows, no register copies)
-    v2f xb[4][kJ];
+    v2f xb[4][J];
     // Loads are unconditional (rows past the end re-read the last row; their data is
     // never used): a load inside a branch gives the paths different numbers of
     // outstanding loads and hipcc then falls back to s_waitcnt vmcnt(0).
@@ -287,10 +299,10 @@ __global__ __launch_bounds__(kStreamThreads, 2) void trk_stream_kernel(
         const float2* row = blk + (size_t)(r < NC ? r : NC - 1) * cs;
         const float4* p = reinterpret_cast<const float4*>(row + mbase);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NLD; ++i) {
             float4 v;
-            if (GEN) v = *reinterpret_cast<const float4*>(row + xo[i]);
-            else v = p[i * 64];                                // 128 samples = 64 float4 apart
+            if (POW2) v = p[i * 64];                           // 128 samples = 64 float4 apart
+            else v = *reinterpret_cast<const float4*>(row + xo[i]);
             dst[2 * i] = v2f{v.x, v.y};
             dst[2 * i + 1] = v2f{v.z, v.w};
         }
@@ -318,12 +330,12 @@ __global__ __launch_bounds__(kStreamThreads, 2) void trk_stream_kernel(
             // every channel, every element: acc[row] += B * x[row]
             if (!(P.flags & 1)) {
 #pragma unroll
-                for (int j = 0; j < kJ; ++j)
+                for (int j = 0; j < J; ++j)
                     cmac6(acc[0][rr], acc[1][rr], acc[2][rr], acc[3][rr], acc[4][rr], acc[5][rr],
                           B[0][j], B[1][j], B[2][j], B[3][j], B[4][j], B[5][j], xc[j]);
             } else {
 #pragma unroll
-                for (int j = 0; j < kJ; ++j) asm volatile("" ::"v"(xc[j]));
+                for (int j = 0; j < J; ++j) asm volatile("" ::"v"(xc[j]));
                 acc[0][rr] += xc[0];
             }
             // the one mixed wave of a channel: the lo elements of the row belong to the
@@ -333,14 +345,19 @@ __global__ __launch_bounds__(kStreamThreads, 2) void trk_stream_kernel(
                 for (int c = 0; c < kGroupCh; ++c) {
                     if (kcls[c] == 2) {
                         v2f sd;
-                        switch (istar[c]) {
-                            case 0: sd = side_sum<0>(B[c], xc, lm0[c], lm1[c]); break;
-                            case 1: sd = side_sum<1>(B[c], xc, lm0[c], lm1[c]); break;
-                            case 2: sd = side_sum<2>(B[c], xc, lm0[c], lm1[c]); break;
-                            default: sd = side_sum<3>(B[c], xc, lm0[c], lm1[c]); break;
+                        if (J == 8) {
+                            switch (istar[c]) {
+                                case 0: sd = side_sum<J, 0>(B[c], xc, lm0[c], lm1[c]); break;
+                                case 1: sd = side_sum<J, 1>(B[c], xc, lm0[c], lm1[c]); break;
+                                case 2: sd = side_sum<J, J == 8 ? 2 : 0>(B[c], xc, lm0[c], lm1[c]); break;
+                                default: sd = side_sum<J, J == 8 ? 3 : 0>(B[c], xc, lm0[c], lm1[c]); break;
+                            }
+                        } else {
+                            if (istar[c] == 0) sd = side_sum<J, 0>(B[c], xc, lm0[c], lm1[c]);
+                            else sd = side_sum<J, 1>(B[c], xc, lm0[c], lm1[c]);
                         }
                         // lo side summed: lo = sd; hi side summed: lo = total - sd
-                        const v2f lo = istar[c] < 2 ? sd : acc[c][rr] - sd;
+                        const v2f lo = side_is_hi<J>(istar[c]) ? acc[c][rr] - sd : sd;
                         acc[c][rr] -= lo;
                         if (rr == 0) carry[c] += lo;
                         else acc[c][rr - 1] += lo;
@@ -348,8 +365,9 @@ __global__ __launch_bounds__(kStreamThreads, 2) void trk_stream_kernel(
                 }
             }
         }
-        // ---- sum over the 64 lanes of the wave: transpose through LDS
-        // (6 channels x 4 rows x re/im = 48 values per lane + 12 carries), fixed order
+        // ---- sum over the 64 lanes of the wave: transpose through LDS in two rounds of
+        // up to 32 columns (6 channels x 4 rows x re/im = 48 values per lane + 12
+        // carries), fixed order
         if (P.flags & 2) {
             if (lane < kTrVals) {
                 const int c = lane / (2 * kPassRows), rr = (lane % (2 * kPassRows)) / 2;
@@ -366,38 +384,51 @@ __global__ __launch_bounds__(kStreamThreads, 2) void trk_stream_kernel(
         // instructions in order, so no workgroup barrier is needed here -- and none
         // is wanted: __syncthreads() would also wait for vmcnt(0) and drain the
         // three rows of loads in flight.
-        __builtin_amdgcn_wave_barrier();
-        {
-            float4* row4 = reinterpret_cast<float4*>(&tr[wave][lane][0]);
+        float4* row4 = reinterpret_cast<float4*>(&tr[wave][lane][0]);
 #pragma unroll
-            for (int c = 0; c < kGroupCh; ++c) {
-                row4[2 * c] = make_float4(acc[c][0].x, acc[c][0].y, acc[c][1].x, acc[c][1].y);
-                row4[2 * c + 1] = make_float4(acc[c][2].x, acc[c][2].y, acc[c][3].x, acc[c][3].y);
+        for (int round = 0; round < kRounds; ++round) {
+            __builtin_amdgcn_wave_barrier();
+            // columns 0..31: channels 0..3; columns 32..59: channels 4, 5 and the carries
+            const int o4 = (kRounds == 2 && round == 1) ? -8 : 0;
+            if (kRounds == 1 || round == 0) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    row4[2 * c] = make_float4(acc[c][0].x, acc[c][0].y, acc[c][1].x, acc[c][1].y);
+                    row4[2 * c + 1] = make_float4(acc[c][2].x, acc[c][2].y, acc[c][3].x, acc[c][3].y);
+                }
             }
+            if (kRounds == 1 || round == 1) {
 #pragma unroll
-            for (int c = 0; c < kGroupCh; c += 2)
-                row4[2 * kGroupCh + c / 2] =
-                    make_float4(carry[c].x, carry[c].y, carry[c + 1].x, carry[c + 1].y);
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (lane < kTrCols) {
-            v2f s2 = v2f{0.f, 0.f};
+                for (int c = 4; c < kGroupCh; ++c) {
+                    row4[o4 + 2 * c] = make_float4(acc[c][0].x, acc[c][0].y, acc[c][1].x, acc[c][1].y);
+                    row4[o4 + 2 * c + 1] =
+                        make_float4(acc[c][2].x, acc[c][2].y, acc[c][3].x, acc[c][3].y);
+                }
+#pragma unroll
+                for (int c = 0; c < kGroupCh; c += 2)
+                    row4[o4 + 12 + c / 2] =
+                        make_float4(carry[c].x, carry[c].y, carry[c + 1].x, carry[c + 1].y);
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int col = kTrHalf * round + lane;            // each lane sums one column
+            if (lane < kTrHalf && col < kTrCols) {
+                v2f s2 = v2f{0.f, 0.f};
 #pragma unroll 8
-            for (int l = 0; l < 64; l += 2) s2 += v2f{tr[wave][l][lane], tr[wave][l + 1][lane]};
-            const float s = s2.x + s2.y;
-            if (lane < kTrVals) {
-                const int c = lane / (2 * kPassRows), rr = (lane % (2 * kPassRows)) / 2;
-                float* dst = reinterpret_cast<float*>(&sw[wq][c][pass * kPassRows + rr]);
-                dst[lane & 1] = s;
-            } else {                        // carries: into the last row of the pass before
-                const int c = (lane - kTrVals) >> 1;
-                float* dst = pass == 0 ? reinterpret_cast<float*>(&hd[wq][c])
-                                       : reinterpret_cast<float*>(&sw[wq][c][pass * kPassRows - 1]);
-                if (pass == 0) dst[lane & 1] = s;
-                else dst[lane & 1] += s;
+                for (int l = 0; l < 64; l += 2) s2 += v2f{tr[wave][l][lane], tr[wave][l + 1][lane]};
+                const float s = s2.x + s2.y;
+                if (col < kTrVals) {
+                    const int c = col / (2 * kPassRows), rr = (col % (2 * kPassRows)) / 2;
+                    float* dst = reinterpret_cast<float*>(&sw[wq][c][pass * kPassRows + rr]);
+                    dst[col & 1] = s;
+                } else {                    // carries: into the last row of the pass before
+                    const int c = (col - kTrVals) >> 1;
+                    float* dst = pass == 0 ? reinterpret_cast<float*>(&hd[wq][c])
+                                           : reinterpret_cast<float*>(&sw[wq][c][pass * kPassRows - 1]);
+                    if (pass == 0) dst[col & 1] = s;
+                    else dst[col & 1] += s;
+                }
             }
         }
-        if (P.flags & 16) __builtin_amdgcn_s_barrier();       // experiment: couple the waves
     }
     __syncthreads();
 
