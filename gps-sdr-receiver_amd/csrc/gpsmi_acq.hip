@@ -84,8 +84,8 @@ __global__ __launch_bounds__(256) void acq_spectrum_kernel(
     const float2* __restrict__ iq, const float* __restrict__ t32,
     const float* __restrict__ omega, int n_avg, float2* __restrict__ spectra,
     const float2* __restrict__ tw) {
-    __shared__ float lds[kFftLdsFloats];
-    __shared__ float lds_tw[kFftTwFloats];
+    __shared__ __attribute__((aligned(16))) float lds[kFftLdsFloats];
+    __shared__ __attribute__((aligned(16))) float lds_tw[kFftTwFloats];
     const int t = threadIdx.x, bin = blockIdx.x;
     const FftTw ftw = fft_setup(lds_tw, tw, t);
     const float om = omega[bin];
@@ -117,10 +117,10 @@ __global__ __launch_bounds__(256) void acq_corr_kernel(
     const float2* __restrict__ spectra, const float2* __restrict__ rep,
     const int* __restrict__ slot, gpsmi_peak* __restrict__ out, int nsv,
     const float2* __restrict__ tw, float2* __restrict__ nbr) {
-    __shared__ float lds[kFftLdsFloats];
+    __shared__ __attribute__((aligned(16))) float lds[kFftLdsFloats];
     __shared__ float red[16];
     __shared__ float nb2[2];
-    __shared__ float lds_tw[kFftTwFloats];
+    __shared__ __attribute__((aligned(16))) float lds_tw[kFftTwFloats];
     const int t = threadIdx.x, sv = blockIdx.x, bin = blockIdx.y;
     const FftTw ftw = fft_setup(lds_tw, tw, t);
     const float2* X = spectra + (size_t)bin * kFftN;

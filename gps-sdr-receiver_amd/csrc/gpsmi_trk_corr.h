@@ -25,8 +25,8 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(
     const int* __restrict__ delay_forced, const float2* __restrict__ rep,
     const float2* __restrict__ tw, TrkParams P, int ngroups, int nblocks,
     gpsmi_trk_out* __restrict__ out, JobMid* __restrict__ mid) {
-    __shared__ float lds[kFftLdsFloats];
-    __shared__ float lds_tw[kFftTwFloats];
+    __shared__ __attribute__((aligned(16))) float lds[kFftLdsFloats];
+    __shared__ __attribute__((aligned(16))) float lds_tw[kFftTwFloats];
     __shared__ float red[20];
     __shared__ float2 urow[CG][32];              // U[c][i], i = row
     __shared__ float2 step[CG];                  // exp(-j w 256/fs)
