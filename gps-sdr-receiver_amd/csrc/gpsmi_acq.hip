@@ -21,63 +21,9 @@
 #include "gpsmi_common.h"
 #include "gpsmi_direct.h"
 #include "gpsmi_fft.h"
+#include "gpsmi_stats.h"
 
 namespace gpsmi {
-
-// ---- wave / workgroup reductions (wave64) ---------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
-}
-
-// larger value wins, ties go to the smaller index (np.argmax, first maximum)
-__device__ __forceinline__ void wave_argmax(float& v, int& i) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        float ov = __shfl_down(v, o, 64);
-        int oi = __shfl_down(i, o, 64);
-        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
-    }
-}
-
-// Statistics of the 2048 magnitudes held as mag[q] = |c[t + 256 q]|.
-// red: >= 16 floats of LDS scratch.  Result valid in every thread.
-__device__ __forceinline__ void corr_stats(const float* mag, int t, float* red,
-                                           int& amax, float& peak, float& mean, float& sd) {
-    const int wave = t >> 6, lane = t & 63;
-    float s = 0.f, bv = mag[0];
-    int bi = t;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        s += mag[q];
-        if (mag[q] > bv) { bv = mag[q]; bi = t + 256 * q; }   // ascending index: strict >
-    }
-    s = wave_sum(s);
-    wave_argmax(bv, bi);
-    __syncthreads();                       // red may still be read by an earlier call
-    if (lane == 0) { red[wave] = s; red[4 + wave] = bv; ((int*)red)[8 + wave] = bi; }
-    __syncthreads();
-    s = (red[0] + red[1]) + (red[2] + red[3]);
-    bv = red[4]; bi = ((int*)red)[8];
-#pragma unroll
-    for (int w = 1; w < 4; ++w) {
-        float ov = red[4 + w];
-        int oi = ((int*)red)[8 + w];
-        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-    }
-    mean = s * (1.0f / kFftN);
-    float d2 = 0.f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { float d = mag[q] - mean; d2 += d * d; }
-    d2 = wave_sum(d2);
-    if (lane == 0) red[12 + wave] = d2;
-    __syncthreads();
-    d2 = (red[12] + red[13]) + (red[14] + red[15]);
-    sd = sqrtf(d2 * (1.0f / kFftN));
-    amax = bi;
-    peak = bv;
-}
 
 // ---- kernels ---------------------------------------------------------------
 __global__ __launch_bounds__(256) void acq_spectrum_kernel(
@@ -118,8 +64,8 @@ __global__ __launch_bounds__(256) void acq_corr_kernel(
     const int* __restrict__ slot, gpsmi_peak* __restrict__ out, int nsv,
     const float2* __restrict__ tw, float2* __restrict__ nbr) {
     __shared__ __attribute__((aligned(16))) float lds[kFftLdsFloats];
-    __shared__ float red[16];
-    __shared__ float nb2[2];
+    __shared__ float red[kStatsRedFloats];
+    __shared__ float magbuf[kFftN];
     __shared__ __attribute__((aligned(16))) float lds_tw[kFftTwFloats];
     const int t = threadIdx.x, sv = blockIdx.x, bin = blockIdx.y;
     const FftTw ftw = fft_setup(lds_tw, tw, t);
@@ -136,22 +82,13 @@ __global__ __launch_bounds__(256) void acq_corr_kernel(
     float mag[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) mag[q] = sqrtf(v[q].x * v[q].x + v[q].y * v[q].y) * (1.0f / kFftN);
-    int amax; float peak, mean, sd;
-    corr_stats(mag, t, red, amax, peak, mean, sd);
-    if (nbr) {                                  // neighbours of the peak, circular
-        const int ia = (amax + kFftN - 1) & (kFftN - 1), ib = (amax + 1) & (kFftN - 1);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            if (t + 256 * q == ia) nb2[0] = mag[q];
-            if (t + 256 * q == ib) nb2[1] = mag[q];
-        }
-        __syncthreads();
-        if (t == 0) nbr[(size_t)bin * nsv + sv] = make_float2(nb2[0], nb2[1]);
-    }
+    int amax; float peak, mean, sd, lo, hi;
+    corr_stats8(mag, t, magbuf, red, amax, peak, mean, sd, lo, hi);
     if (t == 0) {
         // fft(conj Y)[n] = conj(N ifft(Y)[n]): same lag index, no reversal
         gpsmi_peak p; p.argmax = amax; p.peak = peak; p.mean = mean; p.std = sd;
         out[(size_t)bin * nsv + sv] = p;
+        if (nbr) nbr[(size_t)bin * nsv + sv] = make_float2(lo, hi);   // circular neighbours
     }
 }
 

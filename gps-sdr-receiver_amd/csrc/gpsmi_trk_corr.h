@@ -16,6 +16,7 @@
 // the block is decoded with (gpslib.py:1181-1182).
 #pragma once
 #include "gpsmi_fft.h"
+#include "gpsmi_stats.h"
 
 namespace gpsmi {
 
@@ -27,7 +28,8 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(
     gpsmi_trk_out* __restrict__ out, JobMid* __restrict__ mid) {
     __shared__ __attribute__((aligned(16))) float lds[kFftLdsFloats];
     __shared__ __attribute__((aligned(16))) float lds_tw[kFftTwFloats];
-    __shared__ float red[20];
+    __shared__ float red[kStatsRedFloats];
+    __shared__ float magbuf[kFftN];
     __shared__ float2 urow[CG][32];              // U[c][i], i = row
     __shared__ float2 step[CG];                  // exp(-j w 256/fs)
     __shared__ StreamChan schan[CG];
@@ -124,7 +126,8 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(
         float2 rs[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) rs[q] = R[t + 256 * q];
-        __syncthreads();                       // LDS of the previous channel's FFT is free
+        // (the two barriers of the previous channel's statistics already separate its
+        // last FFT reads from the writes below)
         fft2048(v, lds, ftw, t);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -138,55 +141,22 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(
         for (int q = 0; q < 8; ++q)
             mag[q] = sqrtf(v[q].x * v[q].x + v[q].y * v[q].y) * (1.0f / kFftN);
 
-        // mean / std / first-index argmax over the 2048 lags
-        float sm = 0.f, bv = mag[0];
-        int bi = t;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            sm += mag[q];
-            if (mag[q] > bv) { bv = mag[q]; bi = t + 256 * q; }
-        }
-        sm = wave_sum_t(sm);
-        wave_argmax_t(bv, bi);
-        __syncthreads();                       // red[] of the previous channel is consumed
-        if (lane == 0) { red[wave] = sm; red[4 + wave] = bv; ((int*)red)[8 + wave] = bi; }
-        __syncthreads();
-        sm = (red[0] + red[1]) + (red[2] + red[3]);
-        bv = red[4]; bi = ((int*)red)[8];
-#pragma unroll
-        for (int w = 1; w < 4; ++w) {
-            const float ov = red[4 + w];
-            const int oi = ((int*)red)[8 + w];
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-        }
-        const float mean = sm * (1.0f / kFftN);
-        float d2 = 0.f;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { const float d = mag[q] - mean; d2 += d * d; }
-        d2 = wave_sum_t(d2);
-        if (lane == 0) red[12 + wave] = d2;
-        const int ia = (bi + kFftN - 1) & (kFftN - 1), ib = (bi + 1) & (kFftN - 1);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            if (t + 256 * q == ia) red[16] = mag[q];
-            if (t + 256 * q == ib) red[17] = mag[q];
-        }
-        __syncthreads();
+        // mean / std / first-index argmax over the 2048 lags, neighbours of the peak
+        int bi; float bv, mean, sd, elo, ehi;
+        corr_stats8(mag, t, magbuf, red, bi, bv, mean, sd, elo, ehi);
         if (t == 0) {
-            d2 = (red[12] + red[13]) + (red[14] + red[15]);
-            const float sd = sqrtf(d2 * (1.0f / kFftN));
             const float norm = (bv - mean) / sd;
             gpsmi_trk_out& o = out[s.job];
             o.prn = s.prn;
             o.mx = bi;
-            o.epl[0] = red[16]; o.epl[1] = bv; o.epl[2] = red[17];
+            o.epl[0] = elo; o.epl[1] = bv; o.epl[2] = ehi;
             o.corr_mean = mean; o.corr_std = sd;
             o.norm_max_corr = norm;
             int delay = -1;
             double cp = -1.0;
             if (norm > P.corr_min) {
                 delay = bi;
-                cp = fit_code_phase((double)red[16], (double)bv, (double)red[17], bi);
+                cp = fit_code_phase((double)elo, (double)bv, (double)ehi, bi);
             }
             o.delay = delay;
             o.reserved0 = 0;
