@@ -274,7 +274,8 @@ def main():
         gathered = np.zeros(cells * world, dtype=E.PEAK_DTYPE)
 
     trk.replay_load(nb, states, cl_out['delay_used'])
-    pin = E.PinnedArray((nb, N_CH), E.OUT_DTYPE)
+    # two page-locked result buffers: the read-back of step k overlaps the kernels of step k+1
+    pins = [E.PinnedArray((nb, N_CH), E.OUT_DTYPE) for _ in range(2)]
 
     def barrier():
         if dist is not None:
@@ -282,17 +283,20 @@ def main():
         E.sync(local)
 
     corr_ms, total_ms, acq_ms = [], [], []
+    recording = [False]
 
     acq_pin = E.PinnedArray((len(f41), len(shard)), E.PEAK_DTYPE)
 
-    def step(record):
-        # the search (its own handle and stream) and the tracking batch are
-        # independent: both are enqueued, then waited for once
-        acq.engine.search_async(d_iq.ptr, NGPS, shard, f41, 1, acq_pin.array,
-                                d_send.ptr if world > 1 else None)
-        trk.replay_run_async(d_iq.at(trk_base), nb)
-        trk.replay_fetch_async(pin.array)
+    def record_last():
+        t, c = trk.last_ms()
+        total_ms.append(t)
+        corr_ms.append(c)
+
+    def finish_search():
+        """wait for the search enqueued one step ago; gather its peak records"""
         acq.engine.wait()
+        if recording[0]:
+            acq_ms.append(acq.engine.last_ms())
         if use_rccl:
             E.check(lib.gpsmi_comm_allgather_peaks(
                 comm, d_send.ptr, d_recv.ptr, len(f41) * len(shard),
@@ -301,21 +305,41 @@ def main():
             mine = torch.from_numpy(acq_pin.array.view(np.uint8).reshape(-1).copy())
             parts = [torch.empty_like(mine) for _ in range(world)]
             dist.all_gather(parts, mine)
-        trk.wait()
-        if record:
-            t, c = trk.last_ms()
-            total_ms.append(t)
-            corr_ms.append(c)
-            acq_ms.append(acq.engine.last_ms())
 
-    for _ in range(a.warmup):
-        step(False)
+    def step(k, record):
+        # Software pipeline of depth two: the host enqueues step k (search on its own
+        # handle and stream, tracking batch, read-back on the copy stream) and only
+        # then waits for step k-1, so that neither the read-back nor the host's launch
+        # work leaves the GPU idle between steps.
+        if k > 0:
+            finish_search()
+        # device-side order: the search starts when batch k-1 has finished, i.e. it runs
+        # beside the code-phase correlation of batch k and is over before the correlator
+        # (the kernel the roofline is quoted for) starts
+        acq.engine.after(trk)
+        acq.engine.search_async(d_iq.ptr, NGPS, shard, f41, 1, acq_pin.array,
+                                d_send.ptr if world > 1 else None)
+        trk.replay_run_async(d_iq.at(trk_base), nb)
+        trk.replay_fetch_async(pins[k & 1].array)
+        trk.wait_prev()
+        if record and k > 0:
+            record_last()
+
+    for k in range(a.warmup):
+        step(k, False)
+    if a.warmup:
+        finish_search()
+    trk.wait()
     barrier()
+    recording[0] = True
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step(True)
+    for k in range(a.steps):
+        step(k, True)
+    finish_search()                         # the last step: its search, ...
+    trk.wait()                              # ... its kernels and its copy
     barrier()
     dt = time.perf_counter() - t0
+    record_last()
     if dist is not None:
         import torch
         tt = torch.tensor([dt], dtype=torch.float64)
@@ -323,7 +347,7 @@ def main():
         dt = float(tt[0])
 
     # replay must have returned exactly what the closed loop produced
-    same = pin.array.tobytes() == cl_out.tobytes()
+    same = all(p.array.tobytes() == cl_out.tobytes() for p in pins[:min(2, a.steps)])
     nxt = trk.replay_states(nb)
     chained = all(np.array_equal(nxt[:-1][k], states[1:][k])
                   for k in ('delay', 'freq', 'phase', 'phase_locked', 'nps',
@@ -349,7 +373,8 @@ def main():
                              f'{nb} x 32 ms blocks (65536 complex64 each, '
                              f'{samples * 8 / 2**20:.0f} MiB resident in HBM) '
                              'in replay of the closed-loop trajectory, results '
-                             'copied to host; preceded per step by configs[1]: '
+                             'copied to host (the copy of a step overlaps the '
+                             'kernels of the next); preceded per step by configs[1]: '
                              '32 SV x 41 Doppler x 1 ms acquisition search'),
                 'channels': len(chans), 'blocks': nb, 'sample_rate_hz': 2048000,
                 'sharding': ('1 GPU' if world == 1 else
@@ -391,7 +416,8 @@ def main():
         print(json.dumps(line))
         if not (same and chained):
             sys.exit('bench: replay does not reproduce the closed loop')
-    pin.free()
+    for p_ in pins:
+        p_.free()
     acq_pin.free()
     if comm is not None:
         lib.gpsmi_comm_destroy(comm)

@@ -135,10 +135,14 @@ __global__ void acq_peaks_kernel(const DirStats* __restrict__ st, gpsmi_peak* __
 
 using namespace gpsmi;
 
+struct gpsmi_acq;
+namespace gpsmi { HandleSync trk_sync(gpsmi_trk* h); }
+
 struct gpsmi_acq {
     gpsmi_cfg cfg;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t order = nullptr;        // orders other handles' streams behind this one
     float2* d_tw = nullptr;
     float* d_t32 = nullptr;
     float2* d_rep = nullptr;          // [GPSMI_MAX_PRN + 1][cs]
@@ -148,6 +152,13 @@ struct gpsmi_acq {
     float* d_omega = nullptr; int* d_slot = nullptr; gpsmi_peak* d_peaks = nullptr;
     size_t cell_cap = 0;
     float2* d_nbr = nullptr;
+    // page-locked staging of the per-call parameters (two sets: a search can be enqueued
+    // while the previous one still runs; no blocking copy, no use of the null stream)
+    float* h_om[2] = {nullptr, nullptr};
+    int32_t* h_slot[2] = {nullptr, nullptr};
+    hipEvent_t staged[2] = {nullptr, nullptr};
+    bool staged_used[2] = {false, false};
+    int stage = 0;
     // direct (time-domain) path for code_samples != 2048
     bool direct = false;
     float* d_rep_time = nullptr;            // [GPSMI_MAX_PRN + 1][cs]
@@ -160,6 +171,10 @@ struct gpsmi_acq {
 };
 
 extern "C" int gpsmi_acq_wait(gpsmi_acq* h);
+
+namespace gpsmi {
+HandleSync acq_sync(gpsmi_acq* h) { return HandleSync{h->stream, h->order, h->cfg.device}; }
+}  // namespace gpsmi
 
 static int acq_reserve(gpsmi_acq* h, int nbins, int nsv) {
     if ((size_t)nbins > h->spec_cap) {
@@ -197,6 +212,7 @@ int gpsmi_acq_create(const gpsmi_cfg* cfg, gpsmi_acq** out) {
     *out = h;
     h->direct = cfg->code_samples != kFftN;
     GPSMI_HIP(hipStreamCreate(&h->stream));
+    GPSMI_HIP(hipEventCreateWithFlags(&h->order, hipEventDisableTiming));
     GPSMI_HIP(hipEventCreate(&h->ev0));
     GPSMI_HIP(hipEventCreate(&h->ev1));
     std::vector<float2> tw;
@@ -212,6 +228,12 @@ int gpsmi_acq_create(const gpsmi_cfg* cfg, gpsmi_acq** out) {
     GPSMI_HIP(hipMemcpy(h->d_t32, t32.data(), ngps * sizeof(float), hipMemcpyHostToDevice));
     GPSMI_HIP(hipMalloc((void**)&h->d_rep, (size_t)(GPSMI_MAX_PRN + 1) * kFftN * sizeof(float2)));
     GPSMI_HIP(hipMalloc((void**)&h->d_slot, (GPSMI_MAX_PRN + 1) * sizeof(int)));
+    for (int k = 0; k < 2; ++k) {
+        GPSMI_HIP(hipHostMalloc((void**)&h->h_om[k], 65536 * sizeof(float), hipHostMallocDefault));
+        GPSMI_HIP(hipHostMalloc((void**)&h->h_slot[k], (GPSMI_MAX_PRN + 1) * sizeof(int32_t),
+                                hipHostMallocDefault));
+        GPSMI_HIP(hipEventCreateWithFlags(&h->staged[k], hipEventDisableTiming));
+    }
     if (h->direct)
         GPSMI_HIP(hipMalloc((void**)&h->d_rep_time,
                             (size_t)(GPSMI_MAX_PRN + 1) * cfg->code_samples * sizeof(float)));
@@ -227,6 +249,12 @@ int gpsmi_acq_destroy(gpsmi_acq* h) {
                     h->d_xsel, h->d_rsel};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
+    for (int k = 0; k < 2; ++k) {
+        if (h->h_om[k]) (void)hipHostFree(h->h_om[k]);
+        if (h->h_slot[k]) (void)hipHostFree(h->h_slot[k]);
+        if (h->staged[k]) (void)hipEventDestroy(h->staged[k]);
+    }
+    if (h->order) (void)hipEventDestroy(h->order);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -276,13 +304,18 @@ static int acq_search_impl(gpsmi_acq* h, const void* d_iq, size_t n, const int32
     GPSMI_HIP(hipSetDevice(h->cfg.device));
     int rc = acq_reserve(h, nbins, nsv);
     if (rc) return rc;
-    // small parameter uploads are blocking copies: the caller's arrays (and the
-    // temporary below) are consumed before this function returns
-    std::vector<float> om(nbins);
-    for (int b = 0; b < nbins; ++b) om[b] = (float)(2.0 * M_PI * freqs[b]);
-    GPSMI_HIP(hipStreamSynchronize(h->stream));
-    GPSMI_HIP(hipMemcpy(h->d_omega, om.data(), nbins * sizeof(float), hipMemcpyHostToDevice));
-    GPSMI_HIP(hipMemcpy(h->d_slot, prn, nsv * sizeof(int), hipMemcpyHostToDevice));
+    // parameter uploads: the caller's arrays are consumed before this function returns
+    // (copied into page-locked staging), the device copies are ordered on the stream
+    const int sg = h->stage ^= 1;
+    if (h->staged_used[sg]) GPSMI_HIP(hipEventSynchronize(h->staged[sg]));
+    for (int b = 0; b < nbins; ++b) h->h_om[sg][b] = (float)(2.0 * M_PI * freqs[b]);
+    for (int i = 0; i < nsv; ++i) h->h_slot[sg][i] = prn[i];
+    GPSMI_HIP(hipMemcpyAsync(h->d_omega, h->h_om[sg], nbins * sizeof(float), hipMemcpyHostToDevice,
+                             h->stream));
+    GPSMI_HIP(hipMemcpyAsync(h->d_slot, h->h_slot[sg], nsv * sizeof(int), hipMemcpyHostToDevice,
+                             h->stream));
+    GPSMI_HIP(hipEventRecord(h->staged[sg], h->stream));
+    h->staged_used[sg] = true;
     if (h->direct) {
         const size_t cells = (size_t)nbins * nsv;
         if ((size_t)nbins > h->dir_bins) {
@@ -387,6 +420,16 @@ int gpsmi_acq_search_ex(gpsmi_acq* h, const float* iq, size_t n, const int32_t* 
 int gpsmi_acq_last_ms(gpsmi_acq* h, float* ms) {
     GPSMI_REQUIRE(h && ms, "null argument");
     *ms = h->last_ms;
+    return GPSMI_OK;
+}
+
+int gpsmi_acq_after_trk(gpsmi_acq* later, gpsmi_trk* earlier) {
+    GPSMI_REQUIRE(later && earlier, "null handle");
+    const HandleSync e = trk_sync(earlier);
+    GPSMI_REQUIRE(e.device == later->cfg.device, "handles on different devices");
+    GPSMI_HIP(hipSetDevice(e.device));
+    GPSMI_HIP(hipEventRecord(e.order, e.stream));
+    GPSMI_HIP(hipStreamWaitEvent(later->stream, e.order, 0));
     return GPSMI_OK;
 }
 

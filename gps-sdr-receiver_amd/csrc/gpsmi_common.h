@@ -30,6 +30,10 @@ int fail(int code, const char* fmt, ...);
 // exp(-2 pi i k / 2048) computed in double, rounded once.
 void make_twiddles(std::vector<float2>& tw);
 
+// stream of a handle and an event of its own to order another handle's stream behind it
+// (defined next to the handle structs; used by gpsmi_trk_after_acq / gpsmi_acq_after_trk)
+struct HandleSync { hipStream_t stream; hipEvent_t order; int device; };
+
 inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 // Single float32 operations that are never fused into a multiply-add, for code that

@@ -283,7 +283,16 @@ struct gpsmi_trk {
     gpsmi_cfg cfg;
     int max_ch = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t copy_stream = nullptr;   // result read-back, overlaps the next replay run
+    hipEvent_t order = nullptr;          // orders other handles' streams behind this one
+    // two result slots: a replay run writes one while the other is still being copied out
+    struct Slot {
+        gpsmi_trk_out* d_out = nullptr;
+        hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // start, corr done, correlator done, end
+        hipEvent_t ready = nullptr, copied = nullptr;
+        bool copy_pending = false, timing_pending = false;
+    } slot[2];
+    int cur = 0;                         // slot of the latest launch
     float2* d_tw = nullptr;
     float* d_t32 = nullptr;
     float2* d_rep = nullptr;         // [GPSMI_MAX_PRN + 1][cs] spectra
@@ -301,12 +310,10 @@ struct gpsmi_trk {
     int* d_forced = nullptr;
     JobMid* d_mid = nullptr;
     float2* d_partial = nullptr;
-    gpsmi_trk_out* d_out = nullptr;
     float last_total_ms = 0.f, last_corr_ms = 0.f;
     int replay_nb = 0;
     bool replay_forced = false;
-    bool timing_pending = false;
-    int corr_cg = 6;
+    int corr_cg = 4;
     // code_samples != 2048: time-domain correlation + chunked correlator
     bool general = false;
     int stream_j = 8;                // code positions per lane of the correlator (8 or 4)
@@ -318,12 +325,13 @@ struct gpsmi_trk {
 
 static int trk_reserve(gpsmi_trk* h, size_t njobs) {
     if (njobs <= h->njobs_cap) return GPSMI_OK;
-    void* olds[] = {h->d_tab_in, h->d_tab_out, h->d_forced, h->d_mid, h->d_partial, h->d_out,
+    void* olds[] = {h->d_tab_in, h->d_tab_out, h->d_forced, h->d_mid, h->d_partial, h->slot[0].d_out,
+                    h->slot[1].d_out,
                     h->d_fold, h->d_mag, h->d_stats, h->d_xsel, h->d_rsel, h->d_partial_g};
     for (void* p : olds)
         if (p) GPSMI_HIP(hipFree(p));
     h->d_tab_in = h->d_tab_out = nullptr; h->d_forced = nullptr; h->d_mid = nullptr;
-    h->d_partial = nullptr; h->d_out = nullptr; h->njobs_cap = 0;
+    h->d_partial = nullptr; h->slot[0].d_out = h->slot[1].d_out = nullptr; h->njobs_cap = 0;
     h->d_fold = nullptr; h->d_mag = nullptr; h->d_stats = nullptr; h->d_xsel = h->d_rsel = nullptr;
     h->d_partial_g = nullptr;
     if (h->general) {
@@ -342,19 +350,20 @@ static int trk_reserve(gpsmi_trk* h, size_t njobs) {
     GPSMI_HIP(hipMalloc((void**)&h->d_forced, njobs * sizeof(int)));
     GPSMI_HIP(hipMalloc((void**)&h->d_mid, njobs * sizeof(JobMid)));
     GPSMI_HIP(hipMalloc((void**)&h->d_partial, njobs * (h->cfg.n_cyc + 1) * sizeof(float2)));
-    GPSMI_HIP(hipMalloc((void**)&h->d_out, njobs * sizeof(gpsmi_trk_out)));
+    for (auto& sl : h->slot) GPSMI_HIP(hipMalloc((void**)&sl.d_out, njobs * sizeof(gpsmi_trk_out)));
     h->njobs_cap = njobs;
     return GPSMI_OK;
 }
 
 // the three kernels over njobs jobs on the handle's stream, events around them
-static int trk_launch(gpsmi_trk* h, const float2* d_iq, const gpsmi_trk_state* st_in,
-                      gpsmi_trk_state* st_out, const int* forced, int njobs, int nch) {
+static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const float2* d_iq,
+                      const gpsmi_trk_state* st_in, gpsmi_trk_state* st_out, const int* forced,
+                      int njobs, int nch) {
     TrkParams P = h->P;
     P.nch = nch;
     // records of closed channels stay all-zero (prn = 0)
-    GPSMI_HIP(hipMemsetAsync(h->d_out, 0, (size_t)njobs * sizeof(gpsmi_trk_out), h->stream));
-    GPSMI_HIP(hipEventRecord(h->ev[0], h->stream));
+    GPSMI_HIP(hipMemsetAsync(sl.d_out, 0, (size_t)njobs * sizeof(gpsmi_trk_out), h->stream));
+    GPSMI_HIP(hipEventRecord(sl.ev[0], h->stream));
     const int nblocks = njobs / nch;
     const int ngroups = (nch + kGroupCh - 1) / kGroupCh;
     const dim3 sgrid(((nblocks + 7) / 8) * 8 * ngroups);
@@ -370,7 +379,7 @@ static int trk_launch(gpsmi_trk* h, const float2* d_iq, const gpsmi_trk_state* s
         hipLaunchKernelGGL(corr_stats_kernel, dim3(njobs), dim3(256), 0, h->stream, h->d_mag, cs,
                            h->d_stats);
         hipLaunchKernelGGL(trk_decide_kernel, dim3((njobs + 255) / 256), dim3(256), 0, h->stream,
-                           h->d_stats, forced, P, njobs, h->d_out, h->d_mid);
+                           h->d_stats, forced, P, njobs, sl.d_out, h->d_mid);
     } else {
         // channels per correlation workgroup: fewer channels = fewer live accumulators
         // = more workgroups per CU for the barrier-heavy FFT phase (GPSMI_CORR_CG to tune)
@@ -379,15 +388,15 @@ static int trk_launch(gpsmi_trk* h, const float2* d_iq, const gpsmi_trk_state* s
         const dim3 cgrid(((nblocks + 7) / 8) * 8 * ng);
         if (cg == 6)
             hipLaunchKernelGGL(trk_corr_kernel<6>, cgrid, dim3(256), 0, h->stream, d_iq, st_in, forced,
-                               h->d_rep, h->d_tw, P, ng, nblocks, h->d_out, h->d_mid);
+                               h->d_rep, h->d_tw, P, ng, nblocks, sl.d_out, h->d_mid);
         else if (cg == 4)
             hipLaunchKernelGGL(trk_corr_kernel<4>, cgrid, dim3(256), 0, h->stream, d_iq, st_in, forced,
-                               h->d_rep, h->d_tw, P, ng, nblocks, h->d_out, h->d_mid);
+                               h->d_rep, h->d_tw, P, ng, nblocks, sl.d_out, h->d_mid);
         else
             hipLaunchKernelGGL(trk_corr_kernel<2>, cgrid, dim3(256), 0, h->stream, d_iq, st_in, forced,
-                               h->d_rep, h->d_tw, P, ng, nblocks, h->d_out, h->d_mid);
+                               h->d_rep, h->d_tw, P, ng, nblocks, sl.d_out, h->d_mid);
     }
-    GPSMI_HIP(hipEventRecord(h->ev[1], h->stream));
+    GPSMI_HIP(hipEventRecord(sl.ev[1], h->stream));
     // ---- the correlator
     if (!(P.flags & 8) || h->general) {    // default: the register-staged correlator
         const dim3 grid(sgrid.x, h->nchunks), block(kStreamThreads);
@@ -434,11 +443,38 @@ static int trk_launch(gpsmi_trk* h, const float2* d_iq, const gpsmi_trk_state* s
         }
 #undef GPSMI_LAUNCH_LDS
     }
-    GPSMI_HIP(hipEventRecord(h->ev[2], h->stream));
+    GPSMI_HIP(hipEventRecord(sl.ev[2], h->stream));
     hipLaunchKernelGGL(trk_epilogue_kernel, dim3((njobs + 3) / 4), dim3(256), 0, h->stream, st_in,
-                       st_out, h->d_mid, h->d_partial, P, njobs, h->d_out);
+                       st_out, h->d_mid, h->d_partial, P, njobs, sl.d_out);
     GPSMI_HIP(hipGetLastError());
-    GPSMI_HIP(hipEventRecord(h->ev[3], h->stream));
+    GPSMI_HIP(hipEventRecord(sl.ev[3], h->stream));
+    return GPSMI_OK;
+}
+
+namespace gpsmi {
+HandleSync acq_sync(gpsmi_acq* h);
+HandleSync trk_sync(gpsmi_trk* h) { return HandleSync{h->stream, h->order, h->cfg.device}; }
+}  // namespace gpsmi
+
+// kernel times of a finished launch into last_*_ms
+static int trk_take_timing(gpsmi_trk* h, gpsmi_trk::Slot& sl) {
+    if (!sl.timing_pending) return GPSMI_OK;
+    GPSMI_HIP(hipEventElapsedTime(&h->last_total_ms, sl.ev[0], sl.ev[3]));
+    GPSMI_HIP(hipEventElapsedTime(&h->last_corr_ms, sl.ev[1], sl.ev[2]));
+    sl.timing_pending = false;
+    return GPSMI_OK;
+}
+
+// everything enqueued so far (kernels and read-backs) has finished
+static int trk_settle(gpsmi_trk* h) {
+    GPSMI_HIP(hipStreamSynchronize(h->stream));
+    GPSMI_HIP(hipStreamSynchronize(h->copy_stream));
+    for (int k = 0; k < 2; ++k) {          // older slot first: last_*_ms end up with the latest run
+        gpsmi_trk::Slot& sl = h->slot[k == 0 ? (h->cur ^ 1) : h->cur];
+        sl.copy_pending = false;
+        int rc = trk_take_timing(h, sl);
+        if (rc) return rc;
+    }
     return GPSMI_OK;
 }
 
@@ -484,7 +520,13 @@ int gpsmi_trk_create(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk** out) {
     h->nchunks = (cfg->code_samples + 256 * h->stream_j - 1) / (256 * h->stream_j);
     *out = h;
     GPSMI_HIP(hipStreamCreate(&h->stream));
-    for (auto& e : h->ev) GPSMI_HIP(hipEventCreate(&e));
+    GPSMI_HIP(hipStreamCreate(&h->copy_stream));
+    GPSMI_HIP(hipEventCreateWithFlags(&h->order, hipEventDisableTiming));
+    for (auto& sl : h->slot) {
+        for (auto& e : sl.ev) GPSMI_HIP(hipEventCreate(&e));
+        GPSMI_HIP(hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming));
+        GPSMI_HIP(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
+    }
     std::vector<float2> tw;
     make_twiddles(tw);
     GPSMI_HIP(hipMalloc((void**)&h->d_tw, tw.size() * sizeof(float2)));
@@ -521,13 +563,21 @@ int gpsmi_trk_destroy(gpsmi_trk* h) {
     if (!h) return GPSMI_OK;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
     void* bufs[] = {h->d_tw, h->d_t32, h->d_rep, h->d_code, h->d_block, h->d_state, h->d_tab_in,
-                    h->d_tab_out, h->d_forced, h->d_mid, h->d_partial, h->d_out, h->d_fold,
+                    h->d_tab_out, h->d_forced, h->d_mid, h->d_partial, h->slot[0].d_out,
+                    h->slot[1].d_out, h->d_fold,
                     h->d_mag, h->d_stats, h->d_xsel, h->d_rsel, h->d_partial_g};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
-    for (auto e : h->ev)
-        if (e) (void)hipEventDestroy(e);
+    for (auto& sl : h->slot) {
+        for (auto e : sl.ev)
+            if (e) (void)hipEventDestroy(e);
+        if (sl.ready) (void)hipEventDestroy(sl.ready);
+        if (sl.copied) (void)hipEventDestroy(sl.copied);
+    }
+    if (h->order) (void)hipEventDestroy(h->order);
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return GPSMI_OK;
@@ -622,14 +672,19 @@ int gpsmi_trk_process_dev(gpsmi_trk* h, const void* d_iq, size_t n, gpsmi_trk_ou
     GPSMI_HIP(hipSetDevice(h->cfg.device));
     int rc = trk_push_state(h);
     if (rc) return rc;
-    rc = trk_launch(h, (const float2*)d_iq, h->d_state, h->d_state, nullptr, h->max_ch, h->max_ch);
+    rc = trk_settle(h);                    // a replay still in flight owns the slots
+    if (rc) return rc;
+    gpsmi_trk::Slot& sl = h->slot[0];      // the closed loop needs one slot only
+    h->cur = 0;
+    rc = trk_launch(h, sl, (const float2*)d_iq, h->d_state, h->d_state, nullptr, h->max_ch,
+                    h->max_ch);
     if (rc) return rc;
     if (out)
-        GPSMI_HIP(hipMemcpyAsync(out, h->d_out, h->max_ch * sizeof(gpsmi_trk_out),
+        GPSMI_HIP(hipMemcpyAsync(out, sl.d_out, h->max_ch * sizeof(gpsmi_trk_out),
                                  hipMemcpyDeviceToHost, h->stream));
     GPSMI_HIP(hipStreamSynchronize(h->stream));
-    GPSMI_HIP(hipEventElapsedTime(&h->last_total_ms, h->ev[0], h->ev[3]));
-    GPSMI_HIP(hipEventElapsedTime(&h->last_corr_ms, h->ev[1], h->ev[2]));
+    GPSMI_HIP(hipEventElapsedTime(&h->last_total_ms, sl.ev[0], sl.ev[3]));
+    GPSMI_HIP(hipEventElapsedTime(&h->last_corr_ms, sl.ev[1], sl.ev[2]));
     return GPSMI_OK;
 }
 
@@ -678,21 +733,34 @@ int gpsmi_trk_replay_run_async(gpsmi_trk* h, const void* d_iq, int nb) {
                     h->replay_nb);
     GPSMI_HIP(hipSetDevice(h->cfg.device));
     const int nch = h->max_ch;
-    h->timing_pending = true;
-    return trk_launch(h, (const float2*)d_iq, h->d_tab_in, h->d_tab_out,
+    h->cur ^= 1;                           // the other slot may still be on its way to the host
+    gpsmi_trk::Slot& sl = h->slot[h->cur];
+    if (sl.copy_pending) {                 // its previous results must have left first
+        GPSMI_HIP(hipStreamWaitEvent(h->stream, sl.copied, 0));
+        sl.copy_pending = false;
+    }
+    sl.timing_pending = true;
+    return trk_launch(h, sl, (const float2*)d_iq, h->d_tab_in, h->d_tab_out,
                       h->replay_forced ? h->d_forced : nullptr, nb * nch, nch);
 }
 
 int gpsmi_trk_wait(gpsmi_trk* h) {
     GPSMI_REQUIRE(h, "null handle");
     GPSMI_HIP(hipSetDevice(h->cfg.device));
-    GPSMI_HIP(hipStreamSynchronize(h->stream));
-    if (h->timing_pending) {
-        GPSMI_HIP(hipEventElapsedTime(&h->last_total_ms, h->ev[0], h->ev[3]));
-        GPSMI_HIP(hipEventElapsedTime(&h->last_corr_ms, h->ev[1], h->ev[2]));
-        h->timing_pending = false;
+    return trk_settle(h);
+}
+
+int gpsmi_trk_wait_prev(gpsmi_trk* h) {
+    GPSMI_REQUIRE(h, "null handle");
+    GPSMI_HIP(hipSetDevice(h->cfg.device));
+    gpsmi_trk::Slot& sl = h->slot[h->cur ^ 1];
+    if (sl.copy_pending) {
+        GPSMI_HIP(hipEventSynchronize(sl.copied));
+        sl.copy_pending = false;
+    } else if (sl.timing_pending) {
+        GPSMI_HIP(hipEventSynchronize(sl.ev[3]));
     }
-    return GPSMI_OK;
+    return trk_take_timing(h, sl);
 }
 
 int gpsmi_trk_replay_run(gpsmi_trk* h, const void* d_iq, int nb) {
@@ -705,8 +773,15 @@ int gpsmi_trk_replay_fetch_async(gpsmi_trk* h, gpsmi_trk_out* out, size_t n) {
     GPSMI_REQUIRE(h && out, "null argument");
     GPSMI_REQUIRE(n <= (size_t)h->replay_nb * h->max_ch, "more records than the last replay ran");
     GPSMI_HIP(hipSetDevice(h->cfg.device));
-    GPSMI_HIP(hipMemcpyAsync(out, h->d_out, n * sizeof(gpsmi_trk_out), hipMemcpyDeviceToHost,
-                             h->stream));
+    gpsmi_trk::Slot& sl = h->slot[h->cur];
+    // the copy runs on its own stream behind the run that produced the records, so the
+    // next run (other slot) overlaps it
+    GPSMI_HIP(hipEventRecord(sl.ready, h->stream));
+    GPSMI_HIP(hipStreamWaitEvent(h->copy_stream, sl.ready, 0));
+    GPSMI_HIP(hipMemcpyAsync(out, sl.d_out, n * sizeof(gpsmi_trk_out), hipMemcpyDeviceToHost,
+                             h->copy_stream));
+    GPSMI_HIP(hipEventRecord(sl.copied, h->copy_stream));
+    sl.copy_pending = true;
     return GPSMI_OK;
 }
 
@@ -741,6 +816,16 @@ int gpsmi_trk_last_ms(gpsmi_trk* h, float* total_ms, float* correlator_ms) {
     GPSMI_REQUIRE(h, "null handle");
     if (total_ms) *total_ms = h->last_total_ms;
     if (correlator_ms) *correlator_ms = h->last_corr_ms;
+    return GPSMI_OK;
+}
+
+int gpsmi_trk_after_acq(gpsmi_trk* later, gpsmi_acq* earlier) {
+    GPSMI_REQUIRE(later && earlier, "null handle");
+    const HandleSync e = acq_sync(earlier);
+    GPSMI_REQUIRE(e.device == later->cfg.device, "handles on different devices");
+    GPSMI_HIP(hipSetDevice(e.device));
+    GPSMI_HIP(hipEventRecord(e.order, e.stream));
+    GPSMI_HIP(hipStreamWaitEvent(later->stream, e.order, 0));
     return GPSMI_OK;
 }
 

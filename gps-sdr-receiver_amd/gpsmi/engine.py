@@ -187,6 +187,10 @@ class AcqEngine:
     def wait(self):
         check(self.lib.gpsmi_acq_wait(self.h), 'gpsmi_acq_wait')
 
+    def after(self, trk_engine):
+        """Later searches start when the TrkEngine's enqueued work is done."""
+        check(self.lib.gpsmi_acq_after_trk(self.h, trk_engine.h), 'gpsmi_acq_after_trk')
+
     def search_ex(self, iq, prns, freqs, n_avg):
         """search() plus corr[argmax-1], corr[argmax+1] per cell: (table, nbr)."""
         prn_a = np.ascontiguousarray(prns, dtype=np.int32)
@@ -313,6 +317,14 @@ class TrkEngine:
 
     def wait(self):
         check(self.lib.gpsmi_trk_wait(self.h), 'gpsmi_trk_wait')
+
+    def after(self, acq_engine):
+        """Later work of this handle starts when the AcqEngine's enqueued work is done."""
+        check(self.lib.gpsmi_trk_after_acq(self.h, acq_engine.h), 'gpsmi_trk_after_acq')
+
+    def wait_prev(self):
+        """The run before the latest one, and its read-back, are done."""
+        check(self.lib.gpsmi_trk_wait_prev(self.h), 'gpsmi_trk_wait_prev')
 
     def replay_fetch(self, out):
         """out: C-contiguous OUT_DTYPE array (ideally from pinned_array)."""

@@ -237,11 +237,22 @@ int gpsmi_trk_replay_load(gpsmi_trk* h, int nb, const gpsmi_trk_state* table,
                           const int32_t* delay_used);
 int gpsmi_trk_replay_run(gpsmi_trk* h, const void* d_iq, int nb);
 int gpsmi_trk_replay_fetch(gpsmi_trk* h, gpsmi_trk_out* out, size_t n);
-/* Non-blocking run / fetch on the handle's stream and the matching wait; out
- * must be page-locked and stay valid until gpsmi_trk_wait().                  */
+/* Non-blocking run / fetch and the matching waits.  The read-back runs on a copy
+ * stream of its own from one of two result slots, so run k+1 overlaps the copy of
+ * run k: run_async, fetch_async(out_k), wait_prev (= run k-1 and its copy are
+ * done, gpsmi_trk_last_ms reports run k-1), ... , wait (everything is done).  out
+ * must be page-locked and stay valid until the wait that covers it; at most two
+ * runs may be outstanding.                                                     */
 int gpsmi_trk_replay_run_async(gpsmi_trk* h, const void* d_iq, int nb);
 int gpsmi_trk_replay_fetch_async(gpsmi_trk* h, gpsmi_trk_out* out, size_t n);
 int gpsmi_trk_wait(gpsmi_trk* h);
+int gpsmi_trk_wait_prev(gpsmi_trk* h);
+/* Device-side ordering between an acquisition and a tracking handle, no host wait:
+ * what is enqueued on `later` after the call starts when everything enqueued on
+ * `earlier` so far has finished (a search between two tracking batches without the
+ * kernels of the two competing for the CUs).                                    */
+int gpsmi_trk_after_acq(gpsmi_trk* later, gpsmi_acq* earlier);
+int gpsmi_acq_after_trk(gpsmi_acq* later, gpsmi_trk* earlier);
 /* State at the END of every job of the last replay, [nb][nch]: equals the next
  * row of the table when the table is a closed-loop trajectory.               */
 int gpsmi_trk_replay_states(gpsmi_trk* h, gpsmi_trk_state* states, size_t n);

@@ -251,3 +251,31 @@ def test_lds_ring_correlator_variant_agrees(closed_loop, monkeypatch):
         assert np.array_equal(rep[k], outs[:nb][k]), k
     np.testing.assert_allclose(rep['dumps'], outs[:nb]['dumps'], rtol=2e-5, atol=2e-7)
     np.testing.assert_allclose(rep['freq'], outs[:nb]['freq'], atol=1e-3)
+
+
+def test_pipelined_replay_runs_and_readbacks(closed_loop):
+    """run_async / fetch_async / wait_prev: three runs in flight two at a time, every
+    read-back equal to the blocking replay (two result slots, copy stream)."""
+    from gpsmi.engine import DeviceBuffer, PinnedArray, OUT_DTYPE
+    eng, outs, states, blocks = closed_loop
+    nb, nch = outs.shape
+    buf = DeviceBuffer(nb * blocks[0].nbytes)
+    for i, b in enumerate(blocks):
+        buf.upload(b, i * b.nbytes)
+    eng.replay_load(nb, states, outs['delay_used'])
+    pins = [PinnedArray((nb, nch), OUT_DTYPE) for _ in range(2)]
+    got = []
+    for k in range(3):
+        pins[k & 1].array.view(np.uint8)[:] = 0xAB        # poison before it is refilled
+        eng.replay_run_async(buf.ptr, nb)
+        eng.replay_fetch_async(pins[k & 1].array)
+        eng.wait_prev()
+        if k > 0:
+            got.append(pins[(k - 1) & 1].array.tobytes())
+            assert eng.last_ms()[0] > 0
+    eng.wait()
+    got.append(pins[2 & 1].array.tobytes())
+    buf.free()
+    for p in pins:
+        p.free()
+    assert all(g == outs.tobytes() for g in got)
