@@ -383,7 +383,8 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const float2* d_iq,
     } else {
         // channels per correlation workgroup: fewer channels = fewer live accumulators
         // = more workgroups per CU for the barrier-heavy FFT phase (GPSMI_CORR_CG to tune)
-        const int cg = h->corr_cg;
+        // (a single block, the closed loop, is latency-bound: spread it over more CUs)
+        const int cg = nblocks * ((nch + h->corr_cg - 1) / h->corr_cg) < 64 ? 2 : h->corr_cg;
         const int ng = (nch + cg - 1) / cg;
         const dim3 cgrid(((nblocks + 7) / 8) * 8 * ng);
         if (cg == 6)

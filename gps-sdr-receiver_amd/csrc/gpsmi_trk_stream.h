@@ -101,6 +101,25 @@ __device__ __forceinline__ void cmac6(v2f& a0, v2f& a1, v2f& a2, v2f& a3, v2f& a
         : "v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(b4), "v"(b5), "v"(x));
 }
 
+// The same with a[c] = b[c] * x (first sample of a row: no zeroing of the accumulators)
+__device__ __forceinline__ void cmac6_init(v2f& a0, v2f& a1, v2f& a2, v2f& a3, v2f& a4, v2f& a5,
+                                           v2f b0, v2f b1, v2f b2, v2f b3, v2f b4, v2f b5, v2f x) {
+    asm("v_pk_mul_f32 %0, %6, %12 op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %1, %7, %12 op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %2, %8, %12 op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %3, %9, %12 op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %4, %10, %12 op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %5, %11, %12 op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %6, %12, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"
+        "v_pk_fma_f32 %1, %7, %12, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"
+        "v_pk_fma_f32 %2, %8, %12, %2 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"
+        "v_pk_fma_f32 %3, %9, %12, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"
+        "v_pk_fma_f32 %4, %10, %12, %4 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"
+        "v_pk_fma_f32 %5, %11, %12, %5 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+        : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5)
+        : "v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(b4), "v"(b5), "v"(x));
+}
+
 // (cos, -sin) of 2*pi*rev, i.e. exp(-j 2 pi rev), |error| ~ 1e-7.  Exact range
 // reduction in revolutions, octant polynomials (Cephes sinf/cosf coefficients).
 __device__ __forceinline__ float2 phasor_rev(float rev) {
@@ -317,11 +336,7 @@ __global__ __launch_bounds__(kStreamThreads, J == 8 ? 2 : 3) void trk_stream_ker
         v2f acc[kGroupCh][kPassRows];
         v2f carry[kGroupCh];                // lo part of the pass's first row: belongs to the row above
 #pragma unroll
-        for (int c = 0; c < kGroupCh; ++c) {
-            carry[c] = v2f{0.f, 0.f};
-#pragma unroll
-            for (int r = 0; r < kPassRows; ++r) acc[c][r] = v2f{0.f, 0.f};
-        }
+        for (int c = 0; c < kGroupCh; ++c) carry[c] = v2f{0.f, 0.f};
 #pragma unroll
         for (int rr = 0; rr < kPassRows; ++rr) {
             const int r = pass * kPassRows + rr;
@@ -329,14 +344,17 @@ __global__ __launch_bounds__(kStreamThreads, J == 8 ? 2 : 3) void trk_stream_ker
             load_row(xb[(rr + 3) & 3], r + 3);
             // every channel, every element: acc[row] += B * x[row]
             if (!(P.flags & 1)) {
+                cmac6_init(acc[0][rr], acc[1][rr], acc[2][rr], acc[3][rr], acc[4][rr], acc[5][rr],
+                           B[0][0], B[1][0], B[2][0], B[3][0], B[4][0], B[5][0], xc[0]);
 #pragma unroll
-                for (int j = 0; j < J; ++j)
+                for (int j = 1; j < J; ++j)
                     cmac6(acc[0][rr], acc[1][rr], acc[2][rr], acc[3][rr], acc[4][rr], acc[5][rr],
                           B[0][j], B[1][j], B[2][j], B[3][j], B[4][j], B[5][j], xc[j]);
             } else {
 #pragma unroll
                 for (int j = 0; j < J; ++j) asm volatile("" ::"v"(xc[j]));
-                acc[0][rr] += xc[0];
+#pragma unroll
+                for (int c = 0; c < kGroupCh; ++c) acc[c][rr] = c == 0 ? xc[0] : v2f{0.f, 0.f};
             }
             // the one mixed wave of a channel: the lo elements of the row belong to the
             // window of the row above
