@@ -14,6 +14,7 @@ detected.
     python oracle/make_golden.py default    # CODE_SAMPLES=2048,  N_CYC=32
     python oracle/make_golden.py hirate     # CODE_SAMPLES=16368, N_CYC=8
     python oracle/make_golden.py navbits    # Subframe / evalGpsBits on constructed frames
+    python oracle/make_golden.py position   # SatOrbit / SatPos / leastSquaresPos4 / ecefToGeo
 
 The reference binds its configuration at import time (``from gpsglob import``),
 so each configuration runs in its own interpreter.
@@ -277,11 +278,191 @@ def run_navbits():
           'valid frames;', [len(s['frames']) for s in streams], 'frames per stream')
 
 
+def run_position():
+    """The reference's own orbit / code-phase / least-squares functions on a
+    constructed scene -> ref_position.npz.
+
+    Scene: eight satellites with constructed ephemerides above a receiver at
+    (49.082961 N, 8.307581 E, 160 m); the forward model uses the reference's
+    SatPos.ecefCoord for the satellite positions and clocks and the same first-order
+    Sagnac term as its solver, so that the observations (subframe sample times and one
+    code phase per 32-ms stream, noise-free) are consistent with what the fix inverts.
+    Stored: the datagrams, the cleaned code-phase lists that went into
+    SatOrbit.evalCodePhase, every tuple it returned, every leastSquaresPos4 solution,
+    ecefToGeo / geoToEcef samples, the truth."""
+    import json
+    import numpy as np
+    gpsglob, gpslib, gpsrecv = _import_reference(2048, 32)
+    from gpsmi import position as P
+    CS, N_CYC = 2048, 32
+    NGPS, FS = CS * N_CYC, 1000 * CS
+    rng = np.random.default_rng(424242)
+    truth = np.array(gpslib.geoToEcef(49.082961, 8.307581, 160.0))
+    tow0 = 50001                       # first subframe carries tow0: its start is (tow0-1)*6 s
+    T0 = (tow0 - 1) * 6 - 3.123456789  # GPS time of local sample 0
+    sp = gpslib.SatPos()
+
+    def make_eph():
+        return {'weekNum': 290, 'Tgd': float(rng.uniform(-2e-8, 2e-8)), 'Toc': 302400,
+                'af2': 0.0, 'af1': float(rng.uniform(-5e-12, 5e-12)),
+                'af0': float(rng.uniform(-4e-4, 4e-4)), 'IODC': 77, 'satAcc': 0,
+                'Crs': float(rng.uniform(-60, 60)), 'deltaN': float(rng.uniform(3e-9, 6e-9)),
+                'M0': float(rng.uniform(-np.pi, np.pi)), 'Cuc': float(rng.uniform(-3e-6, 3e-6)),
+                'e': float(rng.uniform(0.002, 0.02)), 'Cus': float(rng.uniform(-9e-6, 9e-6)),
+                'sqrtA': float(5153.6 + rng.uniform(-0.3, 0.3)), 'Toe': 302400, 'IODE2': 77,
+                'Cic': float(rng.uniform(-2e-7, 2e-7)),
+                'omegaBig': float(rng.uniform(-np.pi, np.pi)),
+                'Cis': float(rng.uniform(-2e-7, 2e-7)),
+                'i0': float(0.96 + rng.uniform(-0.03, 0.03)),
+                'Crc': float(rng.uniform(150, 350)),
+                'omegaSmall': float(rng.uniform(-np.pi, np.pi)),
+                'omegaDot': float(rng.uniform(-8.6e-9, -7.6e-9)),
+                'IDOT': float(rng.uniform(-5e-10, 5e-10)), 'IODE3': 77}
+
+    up = truth / np.linalg.norm(truth)
+    ephs = {}
+    prn = 1
+    while len(ephs) < 8:               # keep satellites above 15 degrees elevation
+        e = make_eph()
+        x, y, z, _ = sp.ecefCoord(tow0, e)
+        los = np.array([x, y, z]) - truth
+        if los.dot(up) / np.linalg.norm(los) > np.sin(np.radians(15)):
+            prn += int(rng.integers(1, 4))
+            ephs[prn] = e
+
+    om = gpslib.OMEGA_EARTH
+    vrot = np.array([-truth[1] * om, truth[0] * om, 0.0])
+
+    def arrive(eph, m):
+        """local sample time at which the code epoch sent m ms after the first
+        subframe start arrives"""
+        tow, DT = tow0 + m // 6000, (m % 6000) / 1000.0
+        x, y, z, dt_sv = sp.ecefCoord(tow, eph, DT=DT)
+        t_tx = (tow - 1) * 6 + DT - dt_sv
+        X = np.array([x, y, z])
+        tau = 0.07
+        for _ in range(4):
+            tau = np.linalg.norm(X - truth - vrot * tau) / gpslib.GPS_C
+        return (t_tx + tau - T0) * FS
+
+    seconds = 48
+    n_streams = int(seconds / 0.032)
+    n_sub = seconds // 6
+    frames = {}                         # second -> list of frame dicts
+    cps = {s: [] for s in ephs}
+    for s, e in ephs.items():
+        for n in range(n_sub):
+            ST = int(np.floor(arrive(e, 6000 * n)))
+            sid = n % 5 + 1
+            f = {'SAT': s, 'ID': sid, 'tow': tow0 + n, 'ST': ST}
+            if sid == 1:
+                f.update({k: e[k] for k in gpslib.ephemSF1})
+                f['satHealth'] = 0
+            elif sid == 2:
+                f.update({k: e[k] for k in gpslib.ephemSF2})
+            elif sid == 3:
+                f.update({k: e[k] for k in gpslib.ephemSF3})
+            frames.setdefault(int((ST + 6 * FS) // FS), []).append(f)
+        k0 = arrive(e, 0)
+        for sno in range(1, n_streams):
+            mid = sno * NGPS + (N_CYC // 2) * CS
+            m = int(round((mid - k0) / CS))
+            k = arrive(e, m)
+            while k < mid:
+                m += 1
+                k = arrive(e, m)
+            while k >= mid + CS:
+                m -= 1
+                k = arrive(e, m)
+            cps[s].append((sno, float(k - np.floor(k / CS) * CS)))
+    datagrams = []
+    for sec in range(seconds):
+        lo, hi = sec / 0.032, (sec + 1) / 0.032
+        coph = {s: [(n, c) for n, c in cps[s] if lo <= n < hi] for s in ephs}
+        datagrams.append((0, sorted(frames.get(sec, []), key=lambda f: f['SAT']), coph))
+
+    # the reference's classes on the same stream; the lists that go into evalCodePhase are
+    # cleaned by the build's own prep_code_phase (gpseval cannot be imported here)
+    solver = P.PositionSolver(CS, N_CYC)
+    orbits = {s: gpslib.SatOrbit(s) for s in ephs}
+    rec_tuples, rec_cpl, rec_fix = [], [], []
+    mean_pos = None
+    for skipped, frame_lst, coph in datagrams:
+        cpl = solver.prep_code_phase(coph)
+        for sf in frame_lst:
+            solver.orbit(sf['SAT'])                 # keeps solver.orbits in step (phase errors)
+            orbits[sf['SAT']].readFrame(dict(sf))
+        res = []
+        for s in cpl:
+            res += orbits[s].evalCodePhase(list(cpl[s]), relCorr=True)
+        rec_cpl.append({str(s): [[int(n), float(c)] for n, c in cpl[s]] for s in cpl})
+        rec_tuples.append([[float(v) for v in t] for t in res])
+        # fixes exactly as ecefPositions calls the solver (gpseval.py:235-318)
+        fixes = []
+        res_sorted = sorted(res, key=lambda t: (t[1], t[7], t[0]))
+        r = 0
+        while r < len(res_sorted):
+            key = (res_sorted[r][1], res_sorted[r][7])
+            grp = []
+            while r < len(res_sorted) and (res_sorted[r][1], res_sorted[r][7]) == key:
+                grp.append(res_sorted[r])
+                r += 1
+            if len(grp) < 4:
+                continue
+            pos = np.array([g[2:5] for g in grp], dtype=np.float64).T
+            t_rx = np.array([g[5] for g in grp])
+            std = np.array([g[8] for g in grp])
+            start = [0, 0, 0, 0]
+            if mean_pos is not None:
+                start[1:] = mean_pos
+            recp, resid, rng_est, meas = gpslib.leastSquaresPos(
+                4, pos, t_rx, maxResidual=gpsglob.MAX_RESIDUAL, maxIt=gpsglob.LSF_MAX_IT,
+                recPos=start, height=gpsglob.HEIGHT, hDev=gpsglob.HEIGHT_DEV, stdDev=std)
+            if resid[-1] <= gpsglob.MAX_RESIDUAL:
+                fixes.append([float(key[0]), float(key[1])] + [float(v) for v in recp]
+                             + [float(len(resid))])
+        if fixes:
+            mean_pos = list(np.mean(np.array([f[3:6] for f in fixes]), axis=0))
+        rec_fix.append(fixes)
+        for s, lst in coph.items():
+            solver.coph_hist[s] = solver.coph_hist.get(s, []) + list(lst)
+
+    geo = []
+    for v in ([truth[0], truth[1], truth[2]], [4.1e6, 6.2e5, 4.8e6], [-2.7e6, -4.3e6, 3.85e6],
+              [1.2e6, -5.0e6, -3.7e6]):
+        geo.append(list(v) + list(gpslib.ecefToGeo(v)))
+    ecf = [[la, lo, al] + list(gpslib.geoToEcef(la, lo, al))
+           for la, lo, al in ((49.082961, 8.307581, 160.0), (-33.9, 151.2, 30.0), (0.0, 0.0, 0.0))]
+    orb = []
+    for s, e in ephs.items():
+        for tow, DT in ((tow0, 0.0), (tow0 + 3, 2.272), (tow0 + 700, 5.999)):
+            orb.append([s, tow, DT] + [float(v) for v in sp.ecefCoord(tow, e, DT=DT)]
+                       + [float(v) for v in sp.ecefCoord(tow, e, DT=DT, relCorr=False)])
+    nfix = sum(len(f) for f in rec_fix)
+    last = np.array(rec_fix[-1][-1][3:6])
+    path = os.path.join(GOLD, 'ref_position.npz')
+    np.savez_compressed(
+        path, truth=truth, ephs=np.array(json.dumps({str(k): v for k, v in ephs.items()})),
+        datagrams=np.array(json.dumps(
+            [[sk, fl, {str(k): v for k, v in co.items()}] for sk, fl, co in datagrams])),
+        cpl=np.array(json.dumps(rec_cpl)), tuples=np.array(json.dumps(rec_tuples)),
+        fixes=np.array(json.dumps(rec_fix)), geo=np.array(geo), ecf=np.array(ecf),
+        orb=np.array(orb))
+    print(path, os.path.getsize(path), 'bytes;', nfix, 'fixes; last fix off truth by',
+          float(np.linalg.norm(last - truth)), 'm')
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1:
-        run_navbits() if sys.argv[1] == 'navbits' else run(sys.argv[1])
+        if sys.argv[1] == 'navbits':
+            run_navbits()
+        elif sys.argv[1] == 'position':
+            run_position()
+        else:
+            run(sys.argv[1])
     else:
         subprocess.check_call([sys.executable, os.path.abspath(__file__), 'navbits'])
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), 'position'])
         for cfg in ('default', 'hirate'):
             subprocess.check_call([sys.executable, os.path.abspath(__file__),
                                    cfg])
