@@ -11,10 +11,11 @@ acc = defaultdict(lambda: defaultdict(list))
 for f in sorted(glob.glob(root + '/**/*counter_collection.csv', recursive=True)):
     for row in csv.DictReader(open(f)):
         k = row['Kernel_Name'].split('(')[0].replace('gpsmi::', '')
-        tag = f[len(root):].strip('/').split('/')[0].split('_pass')[0]
+        tag = f[len(root):].strip('/').split('/')[0]
+        tag = tag.split('_pass')[0] if '_pass' in tag else ''
         if 'stream' not in k and 'corr' not in k and 'epilogue' not in k:
             continue
-        acc[tag + ' ' + k][row['Counter_Name']].append(float(row['Counter_Value']))
+        acc[(tag + ' ' + k).strip()][row['Counter_Name']].append(float(row['Counter_Value']))
 for k, d in acc.items():
     print(k)
     for c, v in sorted(d.items()):
