@@ -167,3 +167,53 @@ def encode_subframe(words24, ds29=0, ds30=0):
         out[30 * i + 24:30 * i + 30] = p
         ds29, ds30 = int(p[4]), int(p[5])
     return out
+
+
+def _with_zero_tail_parity(word24, ds29, ds30):
+    """Choose the two non-information bits (23, 24) of a word so that its parity bits
+    29 and 30 come out 0 (IS-GPS-200 does this in words 2 and 10: the next word,
+    and the next subframe's preamble, are then never inverted)."""
+    for t in range(4):
+        w = np.array(word24, dtype=np.int8)
+        w[22], w[23] = t >> 1, t & 1
+        p = word_parity(w, ds29, ds30)
+        if p[4] == 0 and p[5] == 0:
+            return w
+    raise ValueError('no solution for the non-information bits')
+
+
+def encode_nav_subframe(sid, tow, eph=None, fill=None):
+    """Test/simulation helper (the reference has no encoder): subframe `sid` (1..5)
+    carrying TOW count `tow` and, for sid 1..3, the fields of `eph` quantised to
+    their IS-GPS-200 LSBs (the inverse of ``extract_subframe``) -> 300 bits whose
+    last two parity bits are 0.  `fill`: optional 10 x 24 array for the bits that
+    carry no field.  Returns (bits, fields_as_decoded)."""
+    w = np.zeros((10, 24), dtype=np.int8) if fill is None else np.array(fill, dtype=np.int8)
+    w[0, :8] = PREAMBLE_BITS
+    w[1, :17] = [(tow >> (16 - i)) & 1 for i in range(17)]
+    w[1, 17:19] = 0
+    w[1, 19:22] = [(sid >> 2) & 1, (sid >> 1) & 1, sid & 1]
+    for name, (parts, signed, scale) in FIELDS[sid].items():
+        nbits = sum(b - a for _, a, b in parts)
+        sc = scale[0] * scale[1] if isinstance(scale, tuple) else scale
+        raw = int(round(eph[name] / sc))
+        lo, hi = (-(1 << (nbits - 1)), (1 << (nbits - 1)) - 1) if signed else (0, (1 << nbits) - 1)
+        if not lo <= raw <= hi:
+            raise ValueError(f'{name} = {eph[name]} does not fit {nbits} bits')
+        raw &= (1 << nbits) - 1
+        bits = [(raw >> (nbits - 1 - i)) & 1 for i in range(nbits)]
+        k = 0
+        for word, a, b in parts:
+            w[word, a:b] = bits[k:k + b - a]
+            k += b - a
+    out = np.zeros(300, dtype=np.int8)
+    ds29 = ds30 = 0
+    for i in range(10):
+        d = _with_zero_tail_parity(w[i], ds29, ds30) if i in (1, 9) else w[i]
+        par = word_parity(d, ds29, ds30)
+        out[30 * i:30 * i + 24] = d ^ ds30
+        out[30 * i + 24:30 * i + 30] = par
+        ds29, ds30 = int(par[4]), int(par[5])
+    status, fields = extract_subframe(out)
+    assert status == NO_ERR
+    return out, fields

@@ -64,6 +64,8 @@ class Sat:
     data_bits: bool = True
     doppler_rate: float = 0.0  # Hz/s
     nav_bits: object = None   # optional 0/1 array: the 50 bit/s message, repeated
+    pos_poly: object = None   # optional (coefs, k0, ks): samples since code epoch 0 as a
+                              # polynomial in (k - k0)/ks (delay following a geometric range)
 
 
 @dataclass
@@ -98,7 +100,11 @@ class Scene:
         for s in self.sats:
             rate = (-s.doppler / 1575.42e6) if s.delay_rate is None \
                 else s.delay_rate
-            pos = k - (s.delay + rate * k)              # samples since code start
+            if s.pos_poly is not None:
+                coefs, k0, ks = s.pos_poly
+                pos = np.polyval(coefs, (k - k0) / ks)
+            else:
+                pos = k - (s.delay + rate * k)          # samples since code start
             period = np.floor(pos / cs)
             off = pos - period * cs
             j = np.floor(off).astype(np.int64)
