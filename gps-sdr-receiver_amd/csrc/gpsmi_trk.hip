@@ -469,7 +469,8 @@ static int trk_take_timing(gpsmi_trk* h, gpsmi_trk::Slot& sl) {
 // everything enqueued so far (kernels and read-backs) has finished
 static int trk_settle(gpsmi_trk* h) {
     GPSMI_HIP(hipStreamSynchronize(h->stream));
-    GPSMI_HIP(hipStreamSynchronize(h->copy_stream));
+    if (h->slot[0].copy_pending || h->slot[1].copy_pending)
+        GPSMI_HIP(hipStreamSynchronize(h->copy_stream));
     for (int k = 0; k < 2; ++k) {          // older slot first: last_*_ms end up with the latest run
         gpsmi_trk::Slot& sl = h->slot[k == 0 ? (h->cur ^ 1) : h->cur];
         sl.copy_pending = false;
@@ -673,8 +674,11 @@ int gpsmi_trk_process_dev(gpsmi_trk* h, const void* d_iq, size_t n, gpsmi_trk_ou
     GPSMI_HIP(hipSetDevice(h->cfg.device));
     int rc = trk_push_state(h);
     if (rc) return rc;
-    rc = trk_settle(h);                    // a replay still in flight owns the slots
-    if (rc) return rc;
+    if (h->slot[0].copy_pending || h->slot[1].copy_pending || h->slot[0].timing_pending ||
+        h->slot[1].timing_pending) {       // a replay still in flight owns the slots
+        rc = trk_settle(h);
+        if (rc) return rc;
+    }
     gpsmi_trk::Slot& sl = h->slot[0];      // the closed loop needs one slot only
     h->cur = 0;
     rc = trk_launch(h, sl, (const float2*)d_iq, h->d_state, h->d_state, nullptr, h->max_ch,
