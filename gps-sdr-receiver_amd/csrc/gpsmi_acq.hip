@@ -15,10 +15,12 @@
 //                         nbins x nsv x 2048 correlation surface never reaches
 //                         HBM; 16 bytes per cell do.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 #include "gpsmi_common.h"
+#include "gpsmi_bigfft.h"
 #include "gpsmi_direct.h"
 #include "gpsmi_fft.h"
 #include "gpsmi_stats.h"
@@ -166,6 +168,9 @@ struct gpsmi_acq {
     float2* d_fold = nullptr; float* d_mag = nullptr; DirStats* d_stats = nullptr;
     int* d_xsel = nullptr; int* d_rsel = nullptr;
     size_t dir_bins = 0, dir_cells = 0;
+    // ... through one 32768-point FFT pair when the code period fits (gpsmi_bigfft.h)
+    bool big = false;
+    float2* d_twN = nullptr; float2* d_RS = nullptr; float2* d_S = nullptr;
     float last_ms = 0.f;
     bool pending = false;
 };
@@ -234,9 +239,23 @@ int gpsmi_acq_create(const gpsmi_cfg* cfg, gpsmi_acq** out) {
                                 hipHostMallocDefault));
         GPSMI_HIP(hipEventCreateWithFlags(&h->staged[k], hipEventDisableTiming));
     }
-    if (h->direct)
+    if (h->direct) {
         GPSMI_HIP(hipMalloc((void**)&h->d_rep_time,
                             (size_t)(GPSMI_MAX_PRN + 1) * cfg->code_samples * sizeof(float)));
+        const char* force = getenv("GPSMI_DIRECT_CORR");          // 1: keep the time-domain kernel
+        h->big = 2 * cfg->code_samples - 1 <= kBigN && !(force && atoi(force) == 1);
+        if (h->big) {
+            std::vector<float2> twn(kBigN);
+            for (int k = 0; k < kBigN; ++k) {
+                const double a = -2.0 * M_PI * (double)k / (double)kBigN;
+                twn[k] = make_float2((float)cos(a), (float)sin(a));
+            }
+            GPSMI_HIP(hipMalloc((void**)&h->d_twN, kBigN * sizeof(float2)));
+            GPSMI_HIP(hipMemcpy(h->d_twN, twn.data(), kBigN * sizeof(float2), hipMemcpyHostToDevice));
+            GPSMI_HIP(hipMalloc((void**)&h->d_RS, (size_t)(GPSMI_MAX_PRN + 1) * kBigN * sizeof(float2)));
+            GPSMI_HIP(hipMalloc((void**)&h->d_S, (size_t)kBigChunkCells * kBigN * sizeof(float2)));
+        }
+    }
     return GPSMI_OK;
 }
 
@@ -246,7 +265,7 @@ int gpsmi_acq_destroy(gpsmi_acq* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* bufs[] = {h->d_tw, h->d_t32, h->d_rep, h->d_iq, h->d_spec, h->d_omega, h->d_slot,
                     h->d_peaks, h->d_nbr, h->d_rep_time, h->d_fold, h->d_mag, h->d_stats,
-                    h->d_xsel, h->d_rsel};
+                    h->d_xsel, h->d_rsel, h->d_twN, h->d_RS, h->d_S};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (int k = 0; k < 2; ++k) {
@@ -269,6 +288,12 @@ int gpsmi_acq_set_replica_time(gpsmi_acq* h, int prn, const float* replica) {
     GPSMI_HIP(hipSetDevice(h->cfg.device));
     GPSMI_HIP(hipMemcpy(h->d_rep_time + (size_t)prn * h->cfg.code_samples, replica,
                         (size_t)h->cfg.code_samples * sizeof(float), hipMemcpyHostToDevice));
+    if (h->big) {
+        big_replica_launch(h->stream, h->d_rep_time, prn, h->cfg.code_samples, h->d_RS, h->d_tw,
+                           h->d_twN);
+        GPSMI_HIP(hipGetLastError());
+        GPSMI_HIP(hipStreamSynchronize(h->stream));
+    }
     h->have_time[prn] = true;
     return GPSMI_OK;
 }
@@ -344,9 +369,14 @@ static int acq_search_impl(gpsmi_acq* h, const void* d_iq, size_t n, const int32
                            (const float2*)d_iq, h->d_t32, h->d_omega, n_avg, cs, h->d_fold);
         hipLaunchKernelGGL(acq_cells_kernel, dim3((ncell + 255) / 256), dim3(256), 0, h->stream,
                            h->d_xsel, h->d_rsel, h->d_slot, nsv, ncell);
-        hipLaunchKernelGGL(circ_corr_direct_kernel,
-                           dim3((cs + kDirLagsPerWg - 1) / kDirLagsPerWg, ncell), dim3(256), 0,
-                           h->stream, h->d_fold, h->d_rep_time, h->d_xsel, h->d_rsel, cs, h->d_mag);
+        if (h->big)
+            big_corr_launch(h->stream, h->d_fold, h->d_xsel, h->d_rsel, ncell, cs, h->d_RS, h->d_S,
+                            h->d_tw, h->d_twN, h->d_mag);
+        else
+            hipLaunchKernelGGL(circ_corr_direct_kernel,
+                               dim3((cs + kDirLagsPerWg - 1) / kDirLagsPerWg, ncell), dim3(256), 0,
+                               h->stream, h->d_fold, h->d_rep_time, h->d_xsel, h->d_rsel, cs,
+                               h->d_mag);
         hipLaunchKernelGGL(corr_stats_kernel, dim3(ncell), dim3(256), 0, h->stream, h->d_mag, cs,
                            h->d_stats);
         hipLaunchKernelGGL(acq_peaks_kernel, dim3((ncell + 255) / 256), dim3(256), 0, h->stream,

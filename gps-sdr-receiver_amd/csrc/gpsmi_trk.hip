@@ -109,6 +109,7 @@ __device__ inline double fit_code_phase(double lo, double pk, double hi, int mx)
 #include "gpsmi_trk_stream.h"
 #include "gpsmi_trk_stream_lds.h"
 #include "gpsmi_trk_corr.h"
+#include "gpsmi_bigfft.h"
 #include "gpsmi_trk_general.h"
 #pragma clang fp contract(off)
 
@@ -320,6 +321,8 @@ struct gpsmi_trk {
     int nchunks = 1;                 // spans of 256 * stream_j positions per code period
     float2* d_fold = nullptr; float* d_mag = nullptr; DirStats* d_stats = nullptr;
     int* d_xsel = nullptr; int* d_rsel = nullptr; float2* d_partial_g = nullptr;
+    bool big = false;                // correlation through the 32768-point FFT pair
+    float2* d_twN = nullptr; float2* d_RS = nullptr; float2* d_S = nullptr;
     TrkParams P;
 };
 
@@ -373,9 +376,14 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const float2* d_iq,
         hipLaunchKernelGGL(trk_fold_general_kernel, dim3((cs + 255) / 256, njobs), dim3(256), 0,
                            h->stream, d_iq, h->d_t32, st_in, P, h->d_fold, h->d_xsel, h->d_rsel,
                            h->d_mid);
-        hipLaunchKernelGGL(circ_corr_direct_kernel,
-                           dim3((cs + kDirLagsPerWg - 1) / kDirLagsPerWg, njobs), dim3(256), 0,
-                           h->stream, h->d_fold, h->d_code, h->d_xsel, h->d_rsel, cs, h->d_mag);
+        if (h->big)
+            big_corr_launch(h->stream, h->d_fold, h->d_xsel, h->d_rsel, njobs, cs, h->d_RS, h->d_S,
+                            h->d_tw, h->d_twN, h->d_mag);
+        else
+            hipLaunchKernelGGL(circ_corr_direct_kernel,
+                               dim3((cs + kDirLagsPerWg - 1) / kDirLagsPerWg, njobs), dim3(256), 0,
+                               h->stream, h->d_fold, h->d_code, h->d_xsel, h->d_rsel, cs,
+                               h->d_mag);
         hipLaunchKernelGGL(corr_stats_kernel, dim3(njobs), dim3(256), 0, h->stream, h->d_mag, cs,
                            h->d_stats);
         hipLaunchKernelGGL(trk_decide_kernel, dim3((njobs + 255) / 256), dim3(256), 0, h->stream,
@@ -543,6 +551,23 @@ int gpsmi_trk_create(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk** out) {
     const size_t code_bytes = (size_t)(GPSMI_MAX_PRN + 1) * cfg->code_samples * sizeof(float);
     GPSMI_HIP(hipMalloc((void**)&h->d_code, code_bytes));
     GPSMI_HIP(hipMemset(h->d_code, 0, code_bytes));          // slot 0: closed channels
+    if (h->general) {
+        const char* force = getenv("GPSMI_DIRECT_CORR");     // 1: keep the time-domain kernel
+        h->big = 2 * cfg->code_samples - 1 <= kBigN && !(force && atoi(force) == 1);
+    }
+    if (h->big) {
+        std::vector<float2> twn(kBigN);
+        for (int k = 0; k < kBigN; ++k) {
+            const double a = -2.0 * M_PI * (double)k / (double)kBigN;
+            twn[k] = make_float2((float)cos(a), (float)sin(a));
+        }
+        GPSMI_HIP(hipMalloc((void**)&h->d_twN, kBigN * sizeof(float2)));
+        GPSMI_HIP(hipMemcpy(h->d_twN, twn.data(), kBigN * sizeof(float2), hipMemcpyHostToDevice));
+        const size_t rs_bytes = (size_t)(GPSMI_MAX_PRN + 1) * kBigN * sizeof(float2);
+        GPSMI_HIP(hipMalloc((void**)&h->d_RS, rs_bytes));
+        GPSMI_HIP(hipMemset(h->d_RS, 0, rs_bytes));          // slot 0: closed channels
+        GPSMI_HIP(hipMalloc((void**)&h->d_S, (size_t)kBigChunkCells * kBigN * sizeof(float2)));
+    }
     GPSMI_HIP(hipMalloc((void**)&h->d_block, (size_t)ngps * sizeof(float2)));
     GPSMI_HIP(hipMalloc((void**)&h->d_state, max_ch * sizeof(gpsmi_trk_state)));
     h->h_state.assign(max_ch, gpsmi_trk_state{});
@@ -569,7 +594,8 @@ int gpsmi_trk_destroy(gpsmi_trk* h) {
     void* bufs[] = {h->d_tw, h->d_t32, h->d_rep, h->d_code, h->d_block, h->d_state, h->d_tab_in,
                     h->d_tab_out, h->d_forced, h->d_mid, h->d_partial, h->slot[0].d_out,
                     h->slot[1].d_out, h->d_fold,
-                    h->d_mag, h->d_stats, h->d_xsel, h->d_rsel, h->d_partial_g};
+                    h->d_mag, h->d_stats, h->d_xsel, h->d_rsel, h->d_partial_g, h->d_twN, h->d_RS,
+                    h->d_S};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto& sl : h->slot) {
@@ -592,9 +618,14 @@ int gpsmi_trk_set_replica(gpsmi_trk* h, int prn, const float* replica, const flo
     const size_t cs = h->cfg.code_samples;
     GPSMI_HIP(hipMemcpy(h->d_code + (size_t)prn * cs, replica, cs * sizeof(float),
                         hipMemcpyHostToDevice));
-    if (!h->general)                       // the time-domain path needs no spectrum
+    if (!h->general)                       // the other path needs no 2048-point spectrum
         GPSMI_HIP(hipMemcpy(h->d_rep + (size_t)prn * kFftN, spectrum, kFftN * sizeof(float2),
                             hipMemcpyHostToDevice));
+    if (h->big) {
+        big_replica_launch(h->stream, h->d_code, prn, (int)cs, h->d_RS, h->d_tw, h->d_twN);
+        GPSMI_HIP(hipGetLastError());
+        GPSMI_HIP(hipStreamSynchronize(h->stream));
+    }
     h->have_rep[prn] = true;
     return GPSMI_OK;
 }
