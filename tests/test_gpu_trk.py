@@ -352,3 +352,43 @@ def test_twenty_channels_four_groups():
         for i, blk in enumerate(blocks):
             assert solo.process(blk)[0].tobytes() == outs[i, c].tobytes(), (c, i)
         solo.close()
+
+
+def test_code_length_4096_matches_the_oracle():
+    """CODE_SAMPLES = 4096 (4.096 Msps), N_CYC = 16: neither the 2048 fast path nor a
+    fixture; acquisition surface and tracking against the oracle on a fresh scene."""
+    import gps_oracle as orc
+    from gpsmi import synth
+    from gpsmi.acquisition import Acquisition
+    from gpsmi.engine import Config, TrkEngine, dumps_of
+    cs, n_cyc = 4096, 16
+    p = orc.Params(code_samples=cs, n_cyc=n_cyc)
+    cfg = Config(code_samples=cs, n_cyc=n_cyc)
+    sc = synth.default_scene(4, seed=57, code_samples=cs, n_cyc=n_cyc, amp=0.09)
+    blocks = [sc.block(b) for b in range(8)]
+    prns = [s.prn for s in sc.sats] + [1]
+    freqs = [round(s.doppler / 200.0) * 200.0 for s in sc.sats]
+    acq = Acquisition(cfg)
+    tab = acq.search_table(blocks[0], prns, freqs, 4)
+    ref = orc.acq_table(blocks[0], freqs, prns, 4, p)
+    acq.engine.close()
+    assert np.array_equal(tab['argmax'], ref['argmax'])
+    for k in ('peak', 'mean', 'std'):
+        np.testing.assert_allclose(tab[k], ref[k], rtol=1e-4)
+    eng = TrkEngine(cfg, max_ch=len(sc.sats))
+    streams = []
+    for c, s in enumerate(sc.sats):
+        d0 = int(tab['argmax'][c, c])
+        eng.open(c, s.prn, freqs[c], d0)
+        streams.append(orc.SatStream(s.prn, freqs[c], p, delay=d0))
+    for i, blk in enumerate(blocks[1:], start=1):
+        out = eng.process(blk)
+        for c, ss in enumerate(streams):
+            ss.process(blk, np.int64((i + 1) * p.ngps))
+            where = f'channel {c} block {i}'
+            assert out[c]['mx'] == ss.last['mx'], where
+            assert out[c]['delay_used'] == ss.delay, where
+            np.testing.assert_allclose(dumps_of(out[c]), ss.last['dumps'], rtol=1e-3,
+                                       atol=1e-5, err_msg=where)
+            assert abs(out[c]['freq'] - ss.freq) < 0.05, where
+    eng.close()
