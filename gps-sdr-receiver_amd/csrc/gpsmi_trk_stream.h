@@ -157,17 +157,46 @@ __device__ __forceinline__ v2f mask_pair(v2f x, unsigned long long m) {
 // chunk); IS is the chunk holding the boundary.  Boundary in the lower half of the
 // chunks: the lo side is summed (chunks below IS whole, chunk IS where the ballot
 // masks say so); in the upper half: the hi side (chunk IS masked, chunks above whole).
+// b * x as a packed pair: the first term of a chain (no zeroed accumulator)
+__device__ __forceinline__ v2f cmul_pk(v2f b, v2f x) {
+    v2f d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+        : "=&v"(d) : "v"(b), "v"(x));
+    return d;
+}
+__device__ __forceinline__ void cmac1(v2f& a, v2f b, v2f x) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+        : "+v"(a) : "v"(b), "v"(x));
+}
+
 template <int J, int IS>
 __device__ __forceinline__ v2f side_sum(const v2f* B, const v2f* x, unsigned long long m0,
                                         unsigned long long m1) {
     constexpr int NCH = J / 2;
     constexpr bool HI = IS >= (NCH + 1) / 2;
-    v2f t0 = v2f{0.f, 0.f}, t1 = v2f{0.f, 0.f};
+    // two chains, each started by a multiplication
+    v2f t0 = cmul_pk(B[2 * IS], mask_pair(x[2 * IS], m0));
+    v2f t1 = cmul_pk(B[2 * IS + 1], mask_pair(x[2 * IS + 1], m1));
 #pragma unroll
     for (int i = 0; i < NCH; ++i)
         if (HI ? i > IS : i < IS) cmac2(t0, t1, B[2 * i], x[2 * i], B[2 * i + 1], x[2 * i + 1]);
-    cmac2(t0, t1, B[2 * IS], mask_pair(x[2 * IS], m0), B[2 * IS + 1], mask_pair(x[2 * IS + 1], m1));
     return t0 + t1;
+}
+// moves the lo part of the row from acc (window r) to prev (window r-1)
+template <int J, int IS>
+__device__ __forceinline__ void side_apply(v2f& acc, v2f& prev, const v2f* B, const v2f* x,
+                                           unsigned long long m0, unsigned long long m1) {
+    constexpr bool HI = IS >= (J / 2 + 1) / 2;
+    const v2f sd = side_sum<J, IS>(B, x, m0, m1);
+    if (HI) {                       // sd = hi part: the rest of the row total is lo
+        prev += acc - sd;
+        acc = sd;
+    } else {                        // sd = lo part
+        acc -= sd;
+        prev += sd;
+    }
 }
 template <int J>
 __device__ __forceinline__ bool side_is_hi(int is) { return is >= (J / 2 + 1) / 2; }
@@ -362,23 +391,18 @@ __global__ __launch_bounds__(kStreamThreads, J == 8 ? 2 : 3) void trk_stream_ker
 #pragma unroll
                 for (int c = 0; c < kGroupCh; ++c) {
                     if (kcls[c] == 2) {
-                        v2f sd;
+                        v2f& prev = rr == 0 ? carry[c] : acc[c][rr == 0 ? 0 : rr - 1];
                         if (J == 8) {
                             switch (istar[c]) {
-                                case 0: sd = side_sum<J, 0>(B[c], xc, lm0[c], lm1[c]); break;
-                                case 1: sd = side_sum<J, 1>(B[c], xc, lm0[c], lm1[c]); break;
-                                case 2: sd = side_sum<J, J == 8 ? 2 : 0>(B[c], xc, lm0[c], lm1[c]); break;
-                                default: sd = side_sum<J, J == 8 ? 3 : 0>(B[c], xc, lm0[c], lm1[c]); break;
+                                case 0: side_apply<J, 0>(acc[c][rr], prev, B[c], xc, lm0[c], lm1[c]); break;
+                                case 1: side_apply<J, 1>(acc[c][rr], prev, B[c], xc, lm0[c], lm1[c]); break;
+                                case 2: side_apply<J, J == 8 ? 2 : 0>(acc[c][rr], prev, B[c], xc, lm0[c], lm1[c]); break;
+                                default: side_apply<J, J == 8 ? 3 : 0>(acc[c][rr], prev, B[c], xc, lm0[c], lm1[c]); break;
                             }
                         } else {
-                            if (istar[c] == 0) sd = side_sum<J, 0>(B[c], xc, lm0[c], lm1[c]);
-                            else sd = side_sum<J, 1>(B[c], xc, lm0[c], lm1[c]);
+                            if (istar[c] == 0) side_apply<J, 0>(acc[c][rr], prev, B[c], xc, lm0[c], lm1[c]);
+                            else side_apply<J, 1>(acc[c][rr], prev, B[c], xc, lm0[c], lm1[c]);
                         }
-                        // lo side summed: lo = sd; hi side summed: lo = total - sd
-                        const v2f lo = side_is_hi<J>(istar[c]) ? acc[c][rr] - sd : sd;
-                        acc[c][rr] -= lo;
-                        if (rr == 0) carry[c] += lo;
-                        else acc[c][rr - 1] += lo;
                     }
                 }
             }
