@@ -454,9 +454,13 @@ __global__ __launch_bounds__(kStreamThreads, J == 8 ? 2 : 3) void trk_stream_ker
             __builtin_amdgcn_wave_barrier();
             const int col = kTrHalf * round + lane;            // each lane sums one column
             if (lane < kTrHalf && col < kTrCols) {
-                v2f s2 = v2f{0.f, 0.f};
-#pragma unroll 8
-                for (int l = 0; l < 64; l += 2) s2 += v2f{tr[wave][l][lane], tr[wave][l + 1][lane]};
+                v2f s2 = v2f{0.f, 0.f}, s3 = v2f{0.f, 0.f};
+#pragma unroll
+                for (int l = 0; l < 64; l += 4) {                  // two chains
+                    s2 += v2f{tr[wave][l][lane], tr[wave][l + 1][lane]};
+                    s3 += v2f{tr[wave][l + 2][lane], tr[wave][l + 3][lane]};
+                }
+                s2 += s3;
                 const float s = s2.x + s2.y;
                 if (col < kTrVals) {
                     const int c = col / (2 * kPassRows), rr = (col % (2 * kPassRows)) / 2;
