@@ -392,3 +392,40 @@ def test_code_length_4096_matches_the_oracle():
                                        atol=1e-5, err_msg=where)
             assert abs(out[c]['freq'] - ss.freq) < 0.05, where
     eng.close()
+
+
+def test_four_positions_per_lane_variant_agrees(closed_loop, monkeypatch):
+    """GPSMI_STREAM_J=4: the correlator with four positions per lane, two position spans
+    per code period and a partial-sum reduction (kept selectable) computes
+    the same windows; only the order of the float32 sums differs."""
+    from gpsmi.engine import TrkEngine, DeviceBuffer
+    _, outs, states, blocks = closed_loop
+    nb, nch = 8, outs.shape[1]
+    monkeypatch.setenv('GPSMI_STREAM_J', '4')
+    eng = TrkEngine(max_ch=nch)
+    monkeypatch.delenv('GPSMI_STREAM_J')
+    buf = DeviceBuffer(nb * blocks[0].nbytes)
+    for i in range(nb):
+        buf.upload(blocks[i], i * blocks[i].nbytes)
+    rep = eng.replay(buf.ptr, nb, states[:nb], outs['delay_used'][:nb])
+    buf.free()
+    eng.close()
+    for k in ('mx', 'delay', 'delay_used', 'n_dumps', 'nps', 'phase_locked'):
+        assert np.array_equal(rep[k], outs[:nb][k]), k
+    np.testing.assert_allclose(rep['dumps'], outs[:nb]['dumps'], rtol=2e-5, atol=2e-7)
+    np.testing.assert_allclose(rep['freq'], outs[:nb]['freq'], atol=1e-3)
+
+
+def test_time_domain_correlation_variant_agrees(closed_loop_hirate, golden_hirate, monkeypatch):
+    """GPSMI_DIRECT_CORR=1: the exact time-domain correlation kernel (the fall-back for
+    code periods beyond 16384 samples) against the same reference fixture as the
+    32768-point FFT path."""
+    from gpsmi.engine import Config, TrkEngine
+    monkeypatch.setenv('GPSMI_DIRECT_CORR', '1')
+    r = _run_closed_loop(golden_hirate, 'hirate', Config(code_samples=16368, n_cyc=8))
+    monkeypatch.delenv('GPSMI_DIRECT_CORR')
+    r[0].close()
+    _check_closed_loop(r[1], golden_hirate)
+    fft = closed_loop_hirate[1]
+    for k in ('mx', 'delay', 'delay_used', 'n_dumps', 'nps', 'phase_locked'):
+        assert np.array_equal(r[1][k], fft[k]), k
