@@ -29,7 +29,7 @@
 //    in registers next to B (6 x 8 complex); after each pass the 64 lanes of a
 //    wave are summed through an LDS transpose (b128 stores, fixed order:
 //    deterministic).  The kernel is bound by VALU issue, not by HBM: the 96 packed
-//    FMAs per wave-row are 60 % of its instruction stream (DESIGN.md section 5).
+//    FMAs per wave-row are 60 % of its instruction stream (DESIGN.md section 4.3).
 //
 // Output: partial[job][0] = head (lo part of row 0, joins the carry from the
 // previous block), partial[job][q+1] = window q (q = 0..NC-2), partial[job][NC]
