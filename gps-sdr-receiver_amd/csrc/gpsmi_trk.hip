@@ -155,6 +155,11 @@ __global__ __launch_bounds__(256) void trk_epilogue_kernel(
             int* b = reinterpret_cast<int*>(&so);
             for (int i = lane; i < (int)(sizeof(gpsmi_trk_state) / 4); i += 64) b[i] = a[i];
         }
+        // the record of a closed channel is all-zero (prn = 0); every byte of an open
+        // channel's record is written by the correlation kernel and below, so the result
+        // buffer needs no memset per launch
+        int* z = reinterpret_cast<int*>(&out[job]);
+        for (int i = lane; i < (int)(sizeof(gpsmi_trk_out) / 4); i += 64) z[i] = 0;
         return;
     }
     gpsmi_trk_out& o = out[job];
@@ -364,8 +369,6 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const float2* d_iq,
                       int njobs, int nch) {
     TrkParams P = h->P;
     P.nch = nch;
-    // records of closed channels stay all-zero (prn = 0)
-    GPSMI_HIP(hipMemsetAsync(sl.d_out, 0, (size_t)njobs * sizeof(gpsmi_trk_out), h->stream));
     GPSMI_HIP(hipEventRecord(sl.ev[0], h->stream));
     const int nblocks = njobs / nch;
     const int ngroups = (nch + kGroupCh - 1) / kGroupCh;

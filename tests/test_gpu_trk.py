@@ -429,3 +429,33 @@ def test_time_domain_correlation_variant_agrees(closed_loop_hirate, golden_hirat
     fft = closed_loop_hirate[1]
     for k in ('mx', 'delay', 'delay_used', 'n_dumps', 'nps', 'phase_locked'):
         assert np.array_equal(r[1][k], fft[k]), k
+
+
+def test_result_slots_carry_nothing_over(closed_loop):
+    """The result buffers are not cleared between launches: every byte of an open
+    channel's record is rewritten and a closed channel's record is zeroed by the
+    epilogue.  A slot that held a full batch is reused for a batch with a closed
+    channel and other data; the read-back equals a fresh engine's."""
+    from gpsmi.engine import TrkEngine, DeviceBuffer
+    eng0, outs, states, blocks = closed_loop
+    nb, nch = 6, outs.shape[1]
+    buf = DeviceBuffer(2 * nb * blocks[0].nbytes)
+    for i in range(2 * nb):
+        buf.upload(blocks[i], i * blocks[i].nbytes)
+    t1, d1 = states[:nb].copy(), outs['delay_used'][:nb].copy()
+    t2, d2 = states[nb:2 * nb].copy(), outs['delay_used'][nb:2 * nb].copy()
+    t2[:, 1] = np.zeros((), dtype=t2.dtype)                     # channel 1 closed in batch 2
+    t2['df_len'][:, 1] = 1
+    second = buf.at(nb * blocks[0].nbytes)
+    fresh = TrkEngine(max_ch=nch)
+    ref = fresh.replay(second, nb, t2, d2).copy()
+    fresh.close()
+    eng = TrkEngine(max_ch=nch)
+    eng.replay(buf.ptr, nb, t1, d1)                             # slot A <- batch 1
+    eng.replay(second, nb, t2, d2)                              # slot B <- batch 2
+    again = eng.replay(second, nb, t2, d2).copy()               # slot A again: held batch 1
+    eng.close()
+    buf.free()
+    assert again.tobytes() == ref.tobytes()
+    assert not np.frombuffer(again[:, 1].tobytes(), dtype=np.uint8).any()   # closed channel: zeros
+    assert (again['prn'][:, 0] > 0).all()
