@@ -299,6 +299,7 @@ struct gpsmi_trk {
         bool copy_pending = false, timing_pending = false;
     } slot[2];
     int cur = 0;                         // slot of the latest launch
+    bool timing = true;                  // record the four kernel-timing events per launch
     float2* d_tw = nullptr;
     float* d_t32 = nullptr;
     float2* d_rep = nullptr;         // [GPSMI_MAX_PRN + 1][cs] spectra
@@ -369,7 +370,8 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const float2* d_iq,
                       int njobs, int nch) {
     TrkParams P = h->P;
     P.nch = nch;
-    GPSMI_HIP(hipEventRecord(sl.ev[0], h->stream));
+    const bool timed = h->timing;        // each event record is a barrier packet (~5 us of bubble)
+    if (timed) GPSMI_HIP(hipEventRecord(sl.ev[0], h->stream));
     const int nblocks = njobs / nch;
     const int ngroups = (nch + kGroupCh - 1) / kGroupCh;
     const dim3 sgrid(((nblocks + 7) / 8) * 8 * ngroups);
@@ -408,7 +410,7 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const float2* d_iq,
             hipLaunchKernelGGL(trk_corr_kernel<2>, cgrid, dim3(256), 0, h->stream, d_iq, st_in, forced,
                                h->d_rep, h->d_tw, P, ng, nblocks, sl.d_out, h->d_mid);
     }
-    GPSMI_HIP(hipEventRecord(sl.ev[1], h->stream));
+    if (timed) GPSMI_HIP(hipEventRecord(sl.ev[1], h->stream));
     // ---- the correlator
     if (!(P.flags & 8) || h->general) {    // default: the register-staged correlator
         const dim3 grid(sgrid.x, h->nchunks), block(kStreamThreads);
@@ -455,11 +457,11 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const float2* d_iq,
         }
 #undef GPSMI_LAUNCH_LDS
     }
-    GPSMI_HIP(hipEventRecord(sl.ev[2], h->stream));
+    if (timed) GPSMI_HIP(hipEventRecord(sl.ev[2], h->stream));
     hipLaunchKernelGGL(trk_epilogue_kernel, dim3((njobs + 3) / 4), dim3(256), 0, h->stream, st_in,
                        st_out, h->d_mid, h->d_partial, P, njobs, sl.d_out);
     GPSMI_HIP(hipGetLastError());
-    GPSMI_HIP(hipEventRecord(sl.ev[3], h->stream));
+    if (timed) GPSMI_HIP(hipEventRecord(sl.ev[3], h->stream));
     return GPSMI_OK;
 }
 
@@ -722,8 +724,10 @@ int gpsmi_trk_process_dev(gpsmi_trk* h, const void* d_iq, size_t n, gpsmi_trk_ou
         GPSMI_HIP(hipMemcpyAsync(out, sl.d_out, h->max_ch * sizeof(gpsmi_trk_out),
                                  hipMemcpyDeviceToHost, h->stream));
     GPSMI_HIP(hipStreamSynchronize(h->stream));
-    GPSMI_HIP(hipEventElapsedTime(&h->last_total_ms, sl.ev[0], sl.ev[3]));
-    GPSMI_HIP(hipEventElapsedTime(&h->last_corr_ms, sl.ev[1], sl.ev[2]));
+    if (h->timing) {
+        GPSMI_HIP(hipEventElapsedTime(&h->last_total_ms, sl.ev[0], sl.ev[3]));
+        GPSMI_HIP(hipEventElapsedTime(&h->last_corr_ms, sl.ev[1], sl.ev[2]));
+    }
     return GPSMI_OK;
 }
 
@@ -778,7 +782,7 @@ int gpsmi_trk_replay_run_async(gpsmi_trk* h, const void* d_iq, int nb) {
         GPSMI_HIP(hipStreamWaitEvent(h->stream, sl.copied, 0));
         sl.copy_pending = false;
     }
-    sl.timing_pending = true;
+    sl.timing_pending = h->timing;
     return trk_launch(h, sl, (const float2*)d_iq, h->d_tab_in, h->d_tab_out,
                       h->replay_forced ? h->d_forced : nullptr, nb * nch, nch);
 }
@@ -865,6 +869,12 @@ int gpsmi_trk_after_acq(gpsmi_trk* later, gpsmi_acq* earlier) {
     GPSMI_HIP(hipSetDevice(e.device));
     GPSMI_HIP(hipEventRecord(e.order, e.stream));
     GPSMI_HIP(hipStreamWaitEvent(later->stream, e.order, 0));
+    return GPSMI_OK;
+}
+
+int gpsmi_trk_set_timing(gpsmi_trk* h, int on) {
+    GPSMI_REQUIRE(h, "null handle");
+    h->timing = on != 0;
     return GPSMI_OK;
 }
 

@@ -322,6 +322,10 @@ class TrkEngine:
         """Later work of this handle starts when the AcqEngine's enqueued work is done."""
         check(self.lib.gpsmi_trk_after_acq(self.h, acq_engine.h), 'gpsmi_trk_after_acq')
 
+    def set_timing(self, on):
+        """Kernel-timing events for the launches that follow (see gpsmi.h)."""
+        check(self.lib.gpsmi_trk_set_timing(self.h, int(bool(on))), 'gpsmi_trk_set_timing')
+
     def wait_prev(self):
         """The run before the latest one, and its read-back, are done."""
         check(self.lib.gpsmi_trk_wait_prev(self.h), 'gpsmi_trk_wait_prev')

@@ -258,6 +258,10 @@ int gpsmi_acq_after_trk(gpsmi_acq* later, gpsmi_trk* earlier);
 int gpsmi_trk_replay_states(gpsmi_trk* h, gpsmi_trk_state* states, size_t n);
 /* Device time of the last process/replay call (HIP events on the handle's
  * stream), total and for the correlator kernel alone, ms.                     */
+/* Kernel-timing events around the launches that follow (default on).  Each of the four
+ * event records is a barrier packet in the queue, ~5 us of pipeline bubble: a caller
+ * that does not read gpsmi_trk_last_ms switches them off, a benchmark samples.   */
+int gpsmi_trk_set_timing(gpsmi_trk* h, int on);
 int gpsmi_trk_last_ms(gpsmi_trk* h, float* total_ms, float* correlator_ms);
 
 /* ========================================================================
