@@ -723,6 +723,9 @@ int gpsmi_trk_process_dev(gpsmi_trk* h, const void* d_iq, size_t n, gpsmi_trk_ou
     if (out)
         GPSMI_HIP(hipMemcpyAsync(out, sl.d_out, h->max_ch * sizeof(gpsmi_trk_out),
                                  hipMemcpyDeviceToHost, h->stream));
+    // nothing to hand back: the block is enqueued, the state stays on the device and the
+    // next call queues behind it (get_state / wait / a call with `out` synchronise)
+    if (!out && !h->timing) return GPSMI_OK;
     GPSMI_HIP(hipStreamSynchronize(h->stream));
     if (h->timing) {
         GPSMI_HIP(hipEventElapsedTime(&h->last_total_ms, sl.ev[0], sl.ev[3]));

@@ -213,7 +213,9 @@ int gpsmi_trk_erase_prev(gpsmi_trk* h, int ch);
 int gpsmi_trk_process(gpsmi_trk* h, const float* iq, size_t n,
                       gpsmi_trk_out* out);
 /* Same on a block that is already in device memory.  out may be NULL when the
- * caller only wants the state to advance (read it later with get_state).      */
+ * caller only wants the state to advance (read it later with get_state); with
+ * the timing events off as well (gpsmi_trk_set_timing) the call returns as soon
+ * as the block is enqueued and consecutive blocks run back to back.            */
 int gpsmi_trk_process_dev(gpsmi_trk* h, const void* d_iq, size_t n,
                           gpsmi_trk_out* out);
 
