@@ -66,13 +66,14 @@ def arrival_sample(eph, truth, tow0, t0_gps, m, fs):
     return (t_tx + tau - t0_gps) * fs
 
 
-def nav_message(eph, tow0, n_subframes, seed):
-    """0/1 bits of `n_subframes` subframes, IDs 1,2,3,4,5,1,... , TOW counts tow0,
-    tow0+1, ... (a TOW count names the start of the NEXT subframe)."""
+def nav_message(eph, tow0, n_subframes, seed, first_sid=1):
+    """0/1 bits of `n_subframes` subframes, IDs first_sid, first_sid+1, ... cycling
+    through 1..5, TOW counts tow0, tow0+1, ... (a TOW count names the start of the
+    NEXT subframe)."""
     rng = np.random.default_rng(seed)
     out = []
     for n in range(n_subframes):
-        sid = n % 5 + 1
+        sid = (n + first_sid - 1) % 5 + 1
         bits, _ = navbits.encode_nav_subframe(sid, tow0 + n, eph,
                                               fill=rng.integers(0, 2, (10, 24)))
         out.append(bits)
@@ -80,7 +81,7 @@ def nav_message(eph, tow0, n_subframes, seed):
 
 
 def geometric_scene(truth, seconds, tow0=50001, lead_s=0.25, n_sats=8, amp=0.11,
-                    noise_sigma=0.35, seed=77, code_samples=2048, n_cyc=32):
+                    noise_sigma=0.35, seed=77, code_samples=2048, n_cyc=32, first_sid=1):
     """(Scene, info): `seconds` of IQ in which subframe `tow0` of every satellite starts
     arriving `lead_s` (+ light-time differences) after sample 0."""
     cs, fs = code_samples, 1000.0 * code_samples
@@ -103,7 +104,7 @@ def geometric_scene(truth, seconds, tow0=50001, lead_s=0.25, n_sats=8, amp=0.11,
         dop0, dop1 = (slope0 - 1.0) * F_L1, (slope1 - 1.0) * F_L1
         sats.append(synth.Sat(prn=prn, doppler=float(dop0), delay=0.0, amp=amp,
                               phase0=0.7 * i, doppler_rate=float((dop1 - dop0) / seconds),
-                              nav_bits=nav_message(eph, tow0, n_sub, seed * 100 + prn),
+                              nav_bits=nav_message(eph, tow0, n_sub, seed * 100 + prn, first_sid),
                               pos_poly=(coefs, k0, ks)))
     scene = synth.Scene(sats=sats, seed=seed, noise_sigma=noise_sigma, code_samples=cs,
                         n_cyc=n_cyc)

@@ -63,3 +63,34 @@ def test_iq_to_position_fix():
     assert mean_err < 5.0
     lat, lon, alt = P.ecef_to_geo(late.mean(axis=0))
     assert abs(lat - 49.082961) < 1e-4 and abs(lon - 8.307581) < 1e-4
+
+
+@pytest.mark.gpu
+def test_cold_start_to_position_fix_without_stored_ephemerides():
+    """The same chain with nothing pre-loaded: the ephemerides come out of the decoded
+    subframes 1-3 of each satellite, then the time references, then the fixes.  The
+    message starts with subframe 5 (lost during lock-in), so 1-3 are complete at ~24 s."""
+    from gpsmi.pipeline import Receiver
+    seconds = 36.0
+    truth = np.array(P.geo_to_ecef(49.082961, 8.307581, 160.0))
+    sc, info = synth_nav.geometric_scene(truth, seconds, seed=78, first_sid=5)
+    rx = Receiver()
+    solver = P.PositionSolver()
+    fixes = []
+    for b in range(int(seconds / 0.032)):
+        dg = rx.feed(sc.block(b))
+        if dg is not None:
+            fixes += solver.feed(pickle.loads(dg))
+    rx.close()
+    ok = [s for s, o in solver.orbits.items() if o.data.ephem_ok]
+    assert len(ok) >= 6
+    for s in ok:                                             # decoded = transmitted (quantised)
+        for k in P.EPHEM_SF1 + P.EPHEM_SF2 + P.EPHEM_SF3:
+            assert solver.orbits[s].data.ephem[k] == info['ephs'][s][k], (s, k)
+    assert len(fixes) > 150, (len(fixes), solver.fail_lst[:3])
+    xyz = np.array([f[1:] for f in fixes])
+    late = xyz[len(xyz) // 2:]
+    mean_err = np.linalg.norm(late.mean(axis=0) - truth)
+    print(f'cold start: {len(ok)} ephemerides decoded, {len(fixes)} fixes, mean of the last '
+          f'{len(late)} off truth by {mean_err:.2f} m')
+    assert mean_err < 5.0
