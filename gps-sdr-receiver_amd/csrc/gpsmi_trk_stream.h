@@ -280,6 +280,32 @@ __global__ __launch_bounds__(kStreamThreads, J == 8 ? 2 : 3) void trk_stream_ker
     int xo[NLD];                                              // load offsets in the row
 #pragma unroll
     for (int i = 0; i < NLD; ++i) xo[i] = (mbase + 128 * i < cs) ? mbase + 128 * i : 0;
+    // ---- the first three rows are requested before B is built: their latency hides
+    // behind the set-up arithmetic
+    // ring of four row buffers with static roles: row r lives in xb[r & 3]; while
+    // row r is processed, row r+3 is loaded into the buffer row r-1 just left
+    // (prefetch distance three rows, no register copies)
+    v2f xb[4][J];
+    // Loads are unconditional (rows past the end re-read the last row; their data is
+    // never used): a load inside a branch gives the paths different numbers of
+    // outstanding loads and hipcc then falls back to s_waitcnt vmcnt(0).
+    auto load_row = [&](v2f* dst, int r) {
+        const float2* row = blk + (size_t)(r < NC ? r : NC - 1) * cs;
+        const float4* p = reinterpret_cast<const float4*>(row + mbase);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            float4 v;
+            if (POW2) v = p[i * 64];                           // 128 samples = 64 float4 apart
+            else v = *reinterpret_cast<const float4*>(row + xo[i]);
+            dst[2 * i] = v2f{v.x, v.y};
+            dst[2 * i + 1] = v2f{v.z, v.w};
+        }
+        __builtin_amdgcn_sched_barrier(0);                     // keep the loads up here
+    };
+    load_row(xb[0], 0);
+    load_row(xb[1], 1);
+    load_row(xb[2], 2);
+
 #pragma unroll
     for (int c = 0; c < kGroupCh; ++c) {
         const int cidx = g * kGroupCh + c;
@@ -335,31 +361,6 @@ __global__ __launch_bounds__(kStreamThreads, J == 8 ? 2 : 3) void trk_stream_ker
         lm0[c] = b0;
         lm1[c] = b1;
     }
-    // ---- stream the rows
-    // ring of four row buffers with static roles: row r lives in xb[r & 3]; while
-    // row r is processed, row r+3 is loaded into the buffer row r-1 just left
-    // (prefetch distance three rows, no register copies)
-    v2f xb[4][J];
-    // Loads are unconditional (rows past the end re-read the last row; their data is
-    // never used): a load inside a branch gives the paths different numbers of
-    // outstanding loads and hipcc then falls back to s_waitcnt vmcnt(0).
-    auto load_row = [&](v2f* dst, int r) {
-        const float2* row = blk + (size_t)(r < NC ? r : NC - 1) * cs;
-        const float4* p = reinterpret_cast<const float4*>(row + mbase);
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            float4 v;
-            if (POW2) v = p[i * 64];                           // 128 samples = 64 float4 apart
-            else v = *reinterpret_cast<const float4*>(row + xo[i]);
-            dst[2 * i] = v2f{v.x, v.y};
-            dst[2 * i + 1] = v2f{v.z, v.w};
-        }
-        __builtin_amdgcn_sched_barrier(0);                     // keep the loads up here
-    };
-    load_row(xb[0], 0);
-    load_row(xb[1], 1);
-    load_row(xb[2], 2);
-
 #pragma unroll 1
     for (int pass = 0; pass < NC / kPassRows; ++pass) {
         v2f acc[kGroupCh][kPassRows];
