@@ -152,6 +152,10 @@ def cpu_baseline(raw, n_blocks, cores):
 
 # ---------------------------------------------------------------------- main
 def main():
+    # stdout carries exactly one JSON line: whatever libraries print there while we run
+    # (gloo's connection banner, for one) is sent to stderr
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
@@ -421,7 +425,8 @@ def main():
         }
         if cpu is not None:
             line['cpu_baseline'] = cpu
-        print(json.dumps(line))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + '\n').encode())
         if not (same and chained):
             sys.exit('bench: replay does not reproduce the closed loop')
     for p_ in pins:
