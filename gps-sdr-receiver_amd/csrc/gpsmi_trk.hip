@@ -108,6 +108,7 @@ __device__ inline double fit_code_phase(double lo, double pk, double hi, int mx)
 #pragma clang fp contract(fast)
 #include "gpsmi_trk_stream.h"
 #include "gpsmi_trk_stream_lds.h"
+#include "gpsmi_trk_stream_mfma.h"
 #include "gpsmi_trk_corr.h"
 #include "gpsmi_bigfft.h"
 #include "gpsmi_trk_general.h"
@@ -324,6 +325,8 @@ struct gpsmi_trk {
     // code_samples != 2048: time-domain correlation + chunked correlator
     bool general = false;
     int stream_j = 8;                // code positions per lane of the correlator (8 or 4)
+    bool mfma = false;               // correlator on the matrix pipe (GPSMI_STREAM_MFMA=1)
+    float* d_code2 = nullptr;        // [GPSMI_MAX_PRN + 1][2 cs]: replica twice (no index wrap)
     int nchunks = 1;                 // spans of 256 * stream_j positions per code period
     float2* d_fold = nullptr; float* d_mag = nullptr; DirStats* d_stats = nullptr;
     int* d_xsel = nullptr; int* d_rsel = nullptr; float2* d_partial_g = nullptr;
@@ -412,7 +415,12 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const float2* d_iq,
     }
     if (timed) GPSMI_HIP(hipEventRecord(sl.ev[1], h->stream));
     // ---- the correlator
-    if (!(P.flags & 8) || h->general) {    // default: the register-staged correlator
+    if (h->mfma) {                         // the correlator on the matrix pipe
+        const int ng12 = (nch + kMfCh - 1) / kMfCh;
+        hipLaunchKernelGGL(trk_stream_mfma_kernel, dim3(((nblocks + 7) / 8) * 8 * ng12),
+                           dim3(64 * kMfWaves), 0,
+                           h->stream, d_iq, h->d_mid, h->d_code2, P, ng12, nblocks, h->d_partial);
+    } else if (!(P.flags & 8) || h->general) {    // default: the register-staged correlator
         const dim3 grid(sgrid.x, h->nchunks), block(kStreamThreads);
         float2* pdst = h->nchunks > 1 ? h->d_partial_g : h->d_partial;
 #define GPSMI_LAUNCH_STREAM(NC, POW2, J)                                                        \
@@ -556,6 +564,15 @@ int gpsmi_trk_create(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk** out) {
     const size_t code_bytes = (size_t)(GPSMI_MAX_PRN + 1) * cfg->code_samples * sizeof(float);
     GPSMI_HIP(hipMalloc((void**)&h->d_code, code_bytes));
     GPSMI_HIP(hipMemset(h->d_code, 0, code_bytes));          // slot 0: closed channels
+    {
+        const char* mf = getenv("GPSMI_STREAM_MFMA");
+        h->mfma = !h->general && cfg->n_cyc == 32 && mf && atoi(mf) == 1;
+        if (h->mfma) {
+            const size_t b2 = (size_t)(GPSMI_MAX_PRN + 1) * 2 * kFftN * sizeof(float);
+            GPSMI_HIP(hipMalloc((void**)&h->d_code2, b2));
+            GPSMI_HIP(hipMemset(h->d_code2, 0, b2));
+        }
+    }
     if (h->general) {
         const char* force = getenv("GPSMI_DIRECT_CORR");     // 1: keep the time-domain kernel
         h->big = 2 * cfg->code_samples - 1 <= kBigN && !(force && atoi(force) == 1);
@@ -600,7 +617,7 @@ int gpsmi_trk_destroy(gpsmi_trk* h) {
                     h->d_tab_out, h->d_forced, h->d_mid, h->d_partial, h->slot[0].d_out,
                     h->slot[1].d_out, h->d_fold,
                     h->d_mag, h->d_stats, h->d_xsel, h->d_rsel, h->d_partial_g, h->d_twN, h->d_RS,
-                    h->d_S};
+                    h->d_S, h->d_code2};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto& sl : h->slot) {
@@ -623,6 +640,12 @@ int gpsmi_trk_set_replica(gpsmi_trk* h, int prn, const float* replica, const flo
     const size_t cs = h->cfg.code_samples;
     GPSMI_HIP(hipMemcpy(h->d_code + (size_t)prn * cs, replica, cs * sizeof(float),
                         hipMemcpyHostToDevice));
+    if (h->mfma) {
+        GPSMI_HIP(hipMemcpy(h->d_code2 + (size_t)prn * 2 * kFftN, replica, kFftN * sizeof(float),
+                            hipMemcpyHostToDevice));
+        GPSMI_HIP(hipMemcpy(h->d_code2 + (size_t)prn * 2 * kFftN + kFftN, replica,
+                            kFftN * sizeof(float), hipMemcpyHostToDevice));
+    }
     if (!h->general)                       // the other path needs no 2048-point spectrum
         GPSMI_HIP(hipMemcpy(h->d_rep + (size_t)prn * kFftN, spectrum, kFftN * sizeof(float2),
                             hipMemcpyHostToDevice));
