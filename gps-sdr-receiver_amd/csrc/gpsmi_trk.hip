@@ -325,7 +325,7 @@ struct gpsmi_trk {
     // code_samples != 2048: time-domain correlation + chunked correlator
     bool general = false;
     int stream_j = 8;                // code positions per lane of the correlator (8 or 4)
-    bool mfma = false;               // correlator on the matrix pipe (GPSMI_STREAM_MFMA=1)
+    bool mfma = false;               // correlator on the matrix pipe (default where it applies)
     float* d_code2 = nullptr;        // [GPSMI_MAX_PRN + 1][2 cs]: replica twice (no index wrap)
     int nchunks = 1;                 // spans of 256 * stream_j positions per code period
     float2* d_fold = nullptr; float* d_mag = nullptr; DirStats* d_stats = nullptr;
@@ -566,7 +566,8 @@ int gpsmi_trk_create(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk** out) {
     GPSMI_HIP(hipMemset(h->d_code, 0, code_bytes));          // slot 0: closed channels
     {
         const char* mf = getenv("GPSMI_STREAM_MFMA");
-        h->mfma = !h->general && cfg->n_cyc == 32 && mf && atoi(mf) == 1;
+        // default for CS = 2048, N_CYC = 32; GPSMI_STREAM_MFMA=0 selects the vector kernel
+        h->mfma = !h->general && cfg->n_cyc == 32 && !(mf && atoi(mf) == 0);
         if (h->mfma) {
             const size_t b2 = (size_t)(GPSMI_MAX_PRN + 1) * 2 * kFftN * sizeof(float);
             GPSMI_HIP(hipMalloc((void**)&h->d_code2, b2));

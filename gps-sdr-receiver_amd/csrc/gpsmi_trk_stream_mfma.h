@@ -1,4 +1,5 @@
-// The tracking correlator on the matrix pipe (selectable: GPSMI_STREAM_MFMA=1).
+// The tracking correlator on the matrix pipe (default for CS = 2048, N_CYC = 32;
+// GPSMI_STREAM_MFMA=0 selects the vector kernel of gpsmi_trk_stream.h).
 //
 // Same mathematics as gpsmi_trk_stream.h -- prompt correlate-and-dump of a 32-ms block,
 // y = roll(replica, delay) * (data * exp(-j(phase + 2 pi f t))) summed per code-period
@@ -16,14 +17,15 @@
 //   so D[r][(c, .)] accumulates sum_m B_c(m) x[r][m] over the positions a wave owns --
 //   no cross-lane reduction, every sample fetched once for all 12 channels.
 //
-// A workgroup = one block x 12 channels, wave w owns positions [512 w, 512 w + 512).  The
-// rows arrive by coalesced 512-byte row segments (tiles of 32 rows x 64 positions),
-// are written to a wave-private LDS tile as two planes (re / im, row pitch 68 floats) and
-// read back transposed, lane = row, four positions per ds_read_b128; two tiles per wave
-// (double buffer, no workgroup barrier in the loop).  B is generated on the VALU in the
-// shadow of the MFMA: a per-lane phasor advanced by one rotation per position (re-seeded
-// exactly at every tile), times the rolled replica sample (doubled table, one dwordx4
-// per four positions), through a per-lane (+-re / +-im) selector.
+// A workgroup = one block x 12 channels, eight waves (two per SIMD: one wave's VALU / LDS
+// work runs beside the other's MFMA), wave w owns positions [256 w, 256 w + 256).  The
+// rows arrive by coalesced 256-byte row segments (tiles of 32 rows x 32 positions), wait
+// in registers for one tile, are written to a wave-private LDS tile as two planes (re /
+// im, row pitch 36 floats) and read back transposed, lane = row, four positions per
+// ds_read_b128 (no workgroup barrier in the loop).  B is generated on the VALU in the
+// shadow of the MFMA: the one real phasor component a lane needs, advanced by a coupled
+// two-FMA recurrence (re-seeded exactly at every tile), times the rolled replica sample
+// (doubled table, staged through LDS per tile).
 //
 // Window q of the reference = positions m >= d of row q plus m < d of row q+1.  A wave
 // keeps ONE accumulator; at m = d_c (a scalar compare per position against the next
@@ -45,6 +47,7 @@ constexpr int kMfPlane = 32 * kMfPitch;   // floats per plane
 constexpr int kMfTileFloats = 2 * kMfPlane;
 
 typedef float mf16 __attribute__((ext_vector_type(16)));
+typedef float mf4u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned b128 load
 
 __device__ __forceinline__ int mf_wave_min(int v) {
 #pragma unroll
@@ -77,6 +80,31 @@ __global__ __launch_bounds__(64 * kMfWaves, 1) void trk_stream_mfma_kernel(
     constexpr int kWavePos = CS / kMfWaves;                    // positions per wave
     const int w0 = kWavePos * wave;
 
+    // ---- tile staging: a lane's share of a tile is 8 float4 (row = idx / 16, two positions each);
+    // the next tile waits in registers while the current one is read from LDS
+    float* tl = &tiles[wave][0];
+    const float2* src = blk + w0;
+    constexpr int kLd = 32 * kMfTile / 2 / 64;                 // float4 per lane and tile
+    float4 st[kLd];
+    auto load_tile = [&](int tix) {
+#pragma unroll
+        for (int i = 0; i < kLd; ++i) {
+            const int idx = i * 64 + lane, r = idx / (kMfTile / 2), c4 = idx % (kMfTile / 2);
+            st[i] = *reinterpret_cast<const float4*>(src + (size_t)r * CS + tix * kMfTile + 2 * c4);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < kLd; ++i) {
+            const int idx = i * 64 + lane, r = idx / (kMfTile / 2), c4 = idx % (kMfTile / 2);
+            float* q = tl + r * kMfPitch + 2 * c4;
+            *reinterpret_cast<float2*>(q) = make_float2(st[i].x, st[i].z);              // re plane
+            *reinterpret_cast<float2*>(q + kMfPlane) = make_float2(st[i].y, st[i].w);   // im plane
+        }
+    };
+    load_tile(0);                          // requested before anything that depends on the job
+                                           // descriptors: HBM latency hides behind the set-up
+
     // ---- lane roles: column j = (channel, re/im), k = which half of the complex sample
     const int j = lane & 31, kk = lane >> 5;
     const int c = j >> 1, part = j & 1;
@@ -105,28 +133,6 @@ __global__ __launch_bounds__(64 * kMfWaves, 1) void trk_stream_mfma_kernel(
     int pb = d <= w0 ? 0 : (d >= w0 + kWavePos ? kWavePos : d - w0);
     if (!active) pb = 0;
 
-    // ---- tile staging: a lane's share of a tile is 8 float4 (row = idx / 16, two positions each);
-    // the next tile waits in registers while the current one is read from LDS
-    float* tl = &tiles[wave][0];
-    const float2* src = blk + w0;
-    constexpr int kLd = 32 * kMfTile / 2 / 64;                 // float4 per lane and tile
-    float4 st[kLd];
-    auto load_tile = [&](int tix) {
-#pragma unroll
-        for (int i = 0; i < kLd; ++i) {
-            const int idx = i * 64 + lane, r = idx / (kMfTile / 2), c4 = idx % (kMfTile / 2);
-            st[i] = *reinterpret_cast<const float4*>(src + (size_t)r * CS + tix * kMfTile + 2 * c4);
-        }
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int i = 0; i < kLd; ++i) {
-            const int idx = i * 64 + lane, r = idx / (kMfTile / 2), c4 = idx % (kMfTile / 2);
-            float* q = tl + r * kMfPitch + 2 * c4;
-            *reinterpret_cast<float2*>(q) = make_float2(st[i].x, st[i].z);              // re plane
-            *reinterpret_cast<float2*>(q + kMfPlane) = make_float2(st[i].y, st[i].w);   // im plane
-        }
-    };
     // The replica samples of a tile (12 channels x 32 positions) go through LDS as well:
     // lane l < 48 fetches 8 consecutive samples of channel l / 4 one tile ahead (before
     // the row loads of the tile after next, so that waiting for them -- loads return in
@@ -144,8 +150,8 @@ __global__ __launch_bounds__(64 * kMfWaves, 1) void trk_stream_mfma_kernel(
     auto load_code = [&](int tix) {
 #pragma unroll
         for (int i = 0; i < kCst; ++i) {
-            const float* q = scp + tix * kMfTile + 4 * i;      // 4-byte aligned only
-            cst[i] = make_float4(q[0], q[1], q[2], q[3]);
+            const mf4u q = *reinterpret_cast<const mf4u*>(scp + tix * kMfTile + 4 * i);
+            cst[i] = make_float4(q.x, q.y, q.z, q.w);
         }
     };
     auto store_code = [&]() {
@@ -157,7 +163,6 @@ __global__ __launch_bounds__(64 * kMfWaves, 1) void trk_stream_mfma_kernel(
         }
     };
     constexpr int kTiles = kWavePos / kMfTile;
-    load_tile(0);
     load_code(0);
 
     mf16 acc, save;

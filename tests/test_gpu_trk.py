@@ -243,8 +243,10 @@ def test_lds_ring_correlator_variant_agrees(closed_loop, monkeypatch):
     _, outs, states, blocks = closed_loop
     nb, nch = 8, outs.shape[1]
     monkeypatch.setenv('GPSMI_DEBUG_FLAGS', '8')
+    monkeypatch.setenv('GPSMI_STREAM_MFMA', '0')
     eng = TrkEngine(max_ch=nch)
     monkeypatch.delenv('GPSMI_DEBUG_FLAGS')
+    monkeypatch.delenv('GPSMI_STREAM_MFMA')
     buf = DeviceBuffer(nb * blocks[0].nbytes)
     for i in range(nb):
         buf.upload(blocks[i], i * blocks[i].nbytes)
@@ -394,6 +396,24 @@ def test_code_length_4096_matches_the_oracle():
     eng.close()
 
 
+def test_vector_correlator_agrees_with_the_matrix_one(closed_loop, golden_default, monkeypatch):
+    """GPSMI_STREAM_MFMA=0: the packed-FMA correlator (the default wherever the matrix-pipe
+    kernel does not apply: other block lengths, other code lengths) on the CS = 2048,
+    N_CYC = 32 fixture: same reference parity, and against the default kernel only the
+    order of the float32 sums differs."""
+    monkeypatch.setenv('GPSMI_STREAM_MFMA', '0')
+    r = _run_closed_loop(golden_default, 'default')
+    monkeypatch.delenv('GPSMI_STREAM_MFMA')
+    r[0].close()
+    _check_closed_loop(r[1], golden_default)
+    outs = closed_loop[1]
+    for k in ('mx', 'delay', 'delay_used', 'n_dumps', 'nps', 'phase_locked'):
+        assert np.array_equal(r[1][k], outs[k]), k
+    # two closed loops: the PLL feeds the last-bit differences back, the trajectories drift
+    # apart within the reference tolerance
+    np.testing.assert_allclose(r[1]['dumps'], outs['dumps'], rtol=1e-3, atol=5e-5)
+
+
 def test_four_positions_per_lane_variant_agrees(closed_loop, monkeypatch):
     """GPSMI_STREAM_J=4: the correlator with four positions per lane, two position spans
     per code period and a partial-sum reduction (kept selectable) computes
@@ -402,8 +422,10 @@ def test_four_positions_per_lane_variant_agrees(closed_loop, monkeypatch):
     _, outs, states, blocks = closed_loop
     nb, nch = 8, outs.shape[1]
     monkeypatch.setenv('GPSMI_STREAM_J', '4')
+    monkeypatch.setenv('GPSMI_STREAM_MFMA', '0')
     eng = TrkEngine(max_ch=nch)
     monkeypatch.delenv('GPSMI_STREAM_J')
+    monkeypatch.delenv('GPSMI_STREAM_MFMA')
     buf = DeviceBuffer(nb * blocks[0].nbytes)
     for i in range(nb):
         buf.upload(blocks[i], i * blocks[i].nbytes)
