@@ -27,7 +27,7 @@ barrier and the max-over-ranks of the step time (gloo); it is not imported at
 N = 1.
 
 The printed JSON line carries `roofline` for the dominant kernel (the
-correlator, trk_stream_kernel: algorithmic bytes = NB*65536*8 per launch, time
+correlator, trk_stream_mfma_kernel: algorithmic bytes = NB*65536*8 per launch, time
 from HIP events on the engine's stream) and `cpu_baseline` (the numpy oracle
 fanned over host cores like the reference's one-process-per-SV pool, on a
 bounded sample of the same blocks; rank 0, N = 1 only).
@@ -64,7 +64,7 @@ def pmc_traffic():
         take = False
         for line in open(path):
             if not line.startswith(' '):
-                take = 'trk_stream_kernel' in line
+                take = 'trk_stream_mfma_kernel' in line
             elif take and 'FETCH_SIZE' in line:
                 fetch = float(line.split()[1])
             elif take and 'WRITE_SIZE' in line:
@@ -395,7 +395,7 @@ def main():
             },
             'x_realtime': round(value / 2.048, 1),
             'roofline': {
-                'bound': 'hbm', 'kernel': 'trk_stream_kernel',
+                'bound': 'hbm', 'kernel': 'trk_stream_mfma_kernel',
                 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
                 'traffic': pmc_traffic() if nb == 1024 else None,

@@ -16,7 +16,7 @@ p = json.load(open(P + 'bench_line_under_rocprof.json'))
 avg = None
 for line in ksum.splitlines():
     c = [x.strip() for x in line.split('|')]
-    if len(c) > 8 and c[1].startswith('trk_stream_kernel') and c[2] == '2048':
+    if len(c) > 8 and c[1].startswith('trk_stream_mfma_kernel') and c[2] == '1024':
         avg = float(c[7])
 ev_p, ev_u = p['kernels_ms']['correlator'] * 1e3, d['kernels_ms']['correlator'] * 1e3
 s = open(P + 'bench_kernel_summary.md').read()
