@@ -325,7 +325,8 @@ struct gpsmi_trk {
     // code_samples != 2048: time-domain correlation + chunked correlator
     bool general = false;
     int stream_j = 8;                // code positions per lane of the correlator (8 or 4)
-    bool mfma = false;               // correlator on the matrix pipe (default where it applies)
+    int mfma = 0;                    // MFMA correlator (default where it applies): 1 = eight waves per
+                                     // workgroup, 3 = four waves, three workgroups per CU
     float* d_code2 = nullptr;        // [GPSMI_MAX_PRN + 1][2 cs]: replica twice (no index wrap)
     int nchunks = 1;                 // spans of 256 * stream_j positions per code period
     float2* d_fold = nullptr; float* d_mag = nullptr; DirStats* d_stats = nullptr;
@@ -417,9 +418,13 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const float2* d_iq,
     // ---- the correlator
     if (h->mfma) {                         // the correlator on the matrix pipe
         const int ng12 = (nch + kMfCh - 1) / kMfCh;
-        hipLaunchKernelGGL(trk_stream_mfma_kernel, dim3(((nblocks + 7) / 8) * 8 * ng12),
-                           dim3(64 * kMfWaves), 0,
-                           h->stream, d_iq, h->d_mid, h->d_code2, P, ng12, nblocks, h->d_partial);
+        const dim3 mgrid(((nblocks + 7) / 8) * 8 * ng12);
+        if (h->mfma == 3)
+            hipLaunchKernelGGL(trk_stream_mfma_kernel<4>, mgrid, dim3(256), 0, h->stream, d_iq,
+                               h->d_mid, h->d_code2, P, ng12, nblocks, h->d_partial);
+        else
+            hipLaunchKernelGGL(trk_stream_mfma_kernel<8>, mgrid, dim3(512), 0, h->stream, d_iq,
+                               h->d_mid, h->d_code2, P, ng12, nblocks, h->d_partial);
     } else if (!(P.flags & 8) || h->general) {    // default: the register-staged correlator
         const dim3 grid(sgrid.x, h->nchunks), block(kStreamThreads);
         float2* pdst = h->nchunks > 1 ? h->d_partial_g : h->d_partial;
@@ -566,8 +571,9 @@ int gpsmi_trk_create(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk** out) {
     GPSMI_HIP(hipMemset(h->d_code, 0, code_bytes));          // slot 0: closed channels
     {
         const char* mf = getenv("GPSMI_STREAM_MFMA");
-        // default for CS = 2048, N_CYC = 32; GPSMI_STREAM_MFMA=0 selects the vector kernel
-        h->mfma = !h->general && cfg->n_cyc == 32 && !(mf && atoi(mf) == 0);
+        // default for CS = 2048, N_CYC = 32; GPSMI_STREAM_MFMA=0 selects the vector kernel,
+        // =3 the four-wave form of the MFMA kernel
+        h->mfma = (!h->general && cfg->n_cyc == 32 && !(mf && atoi(mf) == 0)) ? (mf ? atoi(mf) : 1) : 0;
         if (h->mfma) {
             const size_t b2 = (size_t)(GPSMI_MAX_PRN + 1) * 2 * kFftN * sizeof(float);
             GPSMI_HIP(hipMalloc((void**)&h->d_code2, b2));

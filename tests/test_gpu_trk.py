@@ -414,6 +414,28 @@ def test_vector_correlator_agrees_with_the_matrix_one(closed_loop, golden_defaul
     np.testing.assert_allclose(r[1]['dumps'], outs['dumps'], rtol=1e-3, atol=5e-5)
 
 
+def test_matrix_correlator_four_wave_variant_agrees(closed_loop, monkeypatch):
+    """GPSMI_STREAM_MFMA=3: four waves per workgroup (512 positions each, three workgroups
+    per CU) instead of eight: same products, the float32 sums split in four instead of
+    eight partial chains."""
+    from gpsmi.engine import TrkEngine, DeviceBuffer
+    _, outs, states, blocks = closed_loop
+    nb, nch = 8, outs.shape[1]
+    buf = DeviceBuffer(nb * blocks[0].nbytes)
+    for i in range(nb):
+        buf.upload(blocks[i], i * blocks[i].nbytes)
+    monkeypatch.setenv('GPSMI_STREAM_MFMA', '3')
+    eng = TrkEngine(max_ch=nch)
+    monkeypatch.delenv('GPSMI_STREAM_MFMA')
+    rep = eng.replay(buf.ptr, nb, states[:nb], outs['delay_used'][:nb])
+    eng.close()
+    buf.free()
+    for k in ('mx', 'delay', 'delay_used', 'n_dumps', 'nps', 'phase_locked'):
+        assert np.array_equal(rep[k], outs[:nb][k]), k
+    np.testing.assert_allclose(rep['dumps'], outs[:nb]['dumps'], rtol=2e-5, atol=2e-7)
+    np.testing.assert_allclose(rep['freq'], outs[:nb]['freq'], atol=1e-3)
+
+
 def test_four_positions_per_lane_variant_agrees(closed_loop, monkeypatch):
     """GPSMI_STREAM_J=4: the correlator with four positions per lane, two position spans
     per code period and a partial-sum reduction (kept selectable) computes
