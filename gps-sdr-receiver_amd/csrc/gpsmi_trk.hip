@@ -325,8 +325,8 @@ struct gpsmi_trk {
     // code_samples != 2048: time-domain correlation + chunked correlator
     bool general = false;
     int stream_j = 8;                // code positions per lane of the correlator (8 or 4)
-    int mfma = 0;                    // MFMA correlator (default where it applies): 1 = eight waves per
-                                     // workgroup, 3 = four waves, three workgroups per CU
+    int mfma = 0;                    // MFMA correlator (default where it applies): 3 = four waves per
+                                     // workgroup, three workgroups per CU; 1 = eight waves
     float* d_code2 = nullptr;        // [GPSMI_MAX_PRN + 1][2 cs]: replica twice (no index wrap)
     int nchunks = 1;                 // spans of 256 * stream_j positions per code period
     float2* d_fold = nullptr; float* d_mag = nullptr; DirStats* d_stats = nullptr;
@@ -419,7 +419,7 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const float2* d_iq,
     if (h->mfma) {                         // the correlator on the matrix pipe
         const int ng12 = (nch + kMfCh - 1) / kMfCh;
         const dim3 mgrid(((nblocks + 7) / 8) * 8 * ng12);
-        if (h->mfma == 3)
+        if (h->mfma != 1)
             hipLaunchKernelGGL(trk_stream_mfma_kernel<4>, mgrid, dim3(256), 0, h->stream, d_iq,
                                h->d_mid, h->d_code2, P, ng12, nblocks, h->d_partial);
         else
@@ -571,9 +571,11 @@ int gpsmi_trk_create(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk** out) {
     GPSMI_HIP(hipMemset(h->d_code, 0, code_bytes));          // slot 0: closed channels
     {
         const char* mf = getenv("GPSMI_STREAM_MFMA");
-        // default for CS = 2048, N_CYC = 32; GPSMI_STREAM_MFMA=0 selects the vector kernel,
-        // =3 the four-wave form of the MFMA kernel
-        h->mfma = (!h->general && cfg->n_cyc == 32 && !(mf && atoi(mf) == 0)) ? (mf ? atoi(mf) : 1) : 0;
+        // default for CS = 2048, N_CYC = 32: the MFMA kernel with four waves per workgroup;
+        // GPSMI_STREAM_MFMA=1 selects its eight-wave form (shorter latency for a single block,
+        // lower throughput for a batch), =0 the vector kernel.  One form per handle: the closed
+        // loop and the replay of a handle sum in the same order (bytewise equal results).
+        h->mfma = (!h->general && cfg->n_cyc == 32 && !(mf && atoi(mf) == 0)) ? (mf ? atoi(mf) : 3) : 0;
         if (h->mfma) {
             const size_t b2 = (size_t)(GPSMI_MAX_PRN + 1) * 2 * kFftN * sizeof(float);
             GPSMI_HIP(hipMalloc((void**)&h->d_code2, b2));

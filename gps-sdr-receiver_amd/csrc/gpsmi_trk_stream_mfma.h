@@ -32,7 +32,7 @@
 //
 // The rows arrive by coalesced 256-byte row segments (tiles of 32 rows x 32 positions),
 // wait in registers for one tile, are written to a wave-private LDS tile as they are
-// (interleaved re / im, row pitch 68 dwords) and read back transposed: lane = (row, k),
+// (interleaved re / im, row pitch 66 dwords) and read back transposed: lane = (row, k),
 // two positions of its component per ds_read2_b32 (no workgroup barrier in the loop).  B
 // is one real phasor component per lane: two positions ride in a packed register pair
 // and advance by a coupled recurrence, times the rolled replica samples (doubled table,
@@ -54,7 +54,7 @@ namespace gpsmi {
 
 constexpr int kMfCh = 12;                 // channels per workgroup
 constexpr int kMfTile = 32;               // positions per tile
-constexpr int kMfRowDw = 2 * kMfTile + 4; // dwords per tile row: 16-byte aligned rows
+constexpr int kMfRowDw = 2 * kMfTile + 2; // dwords per tile row: lane = row reads hit every bank twice
 constexpr int kMfTileFloats = 32 * kMfRowDw;
 constexpr int kMfCodePitch = kMfTile + 4; // floats per replica row: b128 reads conflict-free
 constexpr int kMfReseed = 8;              // tiles between exact phasors
@@ -146,8 +146,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void trk_stream_mfm
     };
     auto store_tile = [&]() {
 #pragma unroll
-        for (int i = 0; i < kLd; ++i)
-            *reinterpret_cast<mf4*>(st_dst + i * 4 * kMfRowDw) = st[i];
+        for (int i = 0; i < kLd; ++i) {                  // rows are 8-byte aligned: two b64 writes
+            *reinterpret_cast<mf2*>(st_dst + i * 4 * kMfRowDw) = mf2{st[i].x, st[i].y};
+            *reinterpret_cast<mf2*>(st_dst + i * 4 * kMfRowDw + 2) = mf2{st[i].z, st[i].w};
+        }
     };
     load_tile(0);                          // requested before anything that depends on the job
                                            // descriptors: HBM latency hides behind the set-up

@@ -414,17 +414,17 @@ def test_vector_correlator_agrees_with_the_matrix_one(closed_loop, golden_defaul
     np.testing.assert_allclose(r[1]['dumps'], outs['dumps'], rtol=1e-3, atol=5e-5)
 
 
-def test_matrix_correlator_four_wave_variant_agrees(closed_loop, monkeypatch):
-    """GPSMI_STREAM_MFMA=3: four waves per workgroup (512 positions each, three workgroups
-    per CU) instead of eight: same products, the float32 sums split in four instead of
-    eight partial chains."""
+def test_matrix_correlator_eight_wave_variant_agrees(closed_loop, monkeypatch):
+    """GPSMI_STREAM_MFMA=1: eight waves per workgroup (256 positions each, one workgroup
+    per CU) instead of four: same products, the float32 sums split in eight instead of
+    four partial chains."""
     from gpsmi.engine import TrkEngine, DeviceBuffer
     _, outs, states, blocks = closed_loop
     nb, nch = 8, outs.shape[1]
     buf = DeviceBuffer(nb * blocks[0].nbytes)
     for i in range(nb):
         buf.upload(blocks[i], i * blocks[i].nbytes)
-    monkeypatch.setenv('GPSMI_STREAM_MFMA', '3')
+    monkeypatch.setenv('GPSMI_STREAM_MFMA', '1')
     eng = TrkEngine(max_ch=nch)
     monkeypatch.delenv('GPSMI_STREAM_MFMA')
     rep = eng.replay(buf.ptr, nb, states[:nb], outs['delay_used'][:nb])
