@@ -1,7 +1,11 @@
 // Where does a wave of trk_stream_mfma_kernel spend its cycles?  Compiles the product
 // translation unit with GPSMI_MF_PROF (per-wave clock64 stamps, see gpsmi_trk_stream_mfma.h)
 // and launches the kernel directly on fabricated descriptors.  Tuning aid only.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include tools/probe/mfma_prof.hip -o tools/probe/mfma_prof
+// Also checks both forms of the kernel against a float64 reference kernel.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Igps-sdr-receiver_amd/csrc \
+//         tools/probe/mfma_prof.hip gps-sdr-receiver_amd/csrc/gpsmi_core.hip \
+//         gps-sdr-receiver_amd/csrc/gpsmi_acq.hip -o tools/probe/mfma_prof
+//   tools/probe/mfma_prof 1024 x      (blocks; any second argument adds the 8-block runs)
 #define GPSMI_MF_PROF 1
 #include "../../gps-sdr-receiver_amd/csrc/gpsmi_trk.hip"
 
