@@ -5,6 +5,7 @@
 //   PATTERN 0: wave w owns positions [512 w, 512 w + 512)         (the kernel's)
 //   PATTERN 1: wave w owns tiles w, w + 4, w + 8, ...             (1 KiB of a row per workgroup step)
 //   PATTERN 2: every tile is 8 KiB of consecutive bytes           (what the loads reach on a stream)
+//   PATTERN 3: tile = 16 rows x 64 positions (512-byte row segments), the two row halves in turn
 // Occupancy is set with unused dynamic LDS.  Diagnostic only.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -15,15 +16,19 @@ __global__ __launch_bounds__(256) void tile_read(const char* __restrict__ src, f
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const char* blk = src + (size_t)blockIdx.x * 524288;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(blk), 0, 524288, 0x00020000);
-    const int ld_off = PATTERN == 2 ? lane * 16 : ((lane >> 4) * 2048 + 2 * (lane & 15)) * 8;
+    const int ld_off = PATTERN == 2 ? lane * 16
+                     : PATTERN == 3 ? ((lane >> 5) * 2048 + 2 * (lane & 31)) * 8
+                                    : ((lane >> 4) * 2048 + 2 * (lane & 15)) * 8;
     mf4 st[8];
     auto load = [&](int tix) {
         const int tb = PATTERN == 0 ? (512 * wave + 32 * tix) * 8
-                     : PATTERN == 1 ? (4 * tix + wave) * 32 * 8 : (16 * wave + tix) * 8192;
+                     : PATTERN == 1 ? (4 * tix + wave) * 32 * 8
+                     : PATTERN == 3 ? (512 * wave + 64 * (tix >> 1)) * 8 + (tix & 1) * 16 * 2048 * 8
+                                    : (16 * wave + tix) * 8192;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             st[i] = __builtin_bit_cast(mf4, __builtin_amdgcn_raw_buffer_load_b128(
-                rs, ld_off, tb + i * (PATTERN == 2 ? 1024 : 4 * 2048 * 8), 0));
+                rs, ld_off, tb + i * (PATTERN == 2 ? 1024 : PATTERN == 3 ? 2 * 2048 * 8 : 4 * 2048 * 8), 0));
     };
     load(0);
     float acc = 0.f;
@@ -58,11 +63,13 @@ int main() {
     hipFuncSetAttribute((const void*)tile_read<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     hipFuncSetAttribute((const void*)tile_read<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     hipFuncSetAttribute((const void*)tile_read<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipFuncSetAttribute((const void*)tile_read<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     for (int dyn : {53000, 40000, 20000})          // 3, 4, 8 workgroups per CU
         for (int spin : {0, 4, 8}) {
             run<0>("wave = 512 consecutive positions (kernel)", d, o, dyn, spin);
             run<1>("waves interleave tiles (1 KiB of a row)", d, o, dyn, spin);
             run<2>("8 KiB consecutive per tile", d, o, dyn, spin);
+            run<3>("16 rows x 512 B per tile", d, o, dyn, spin);
         }
     return 0;
 }
