@@ -109,6 +109,7 @@ __device__ inline double fit_code_phase(double lo, double pk, double hi, int mx)
 #include "gpsmi_trk_stream.h"
 #include "gpsmi_trk_stream_lds.h"
 #include "gpsmi_trk_stream_mfma.h"
+#include "gpsmi_trk_span.h"
 #include "gpsmi_trk_corr.h"
 #include "gpsmi_bigfft.h"
 #include "gpsmi_trk_general.h"

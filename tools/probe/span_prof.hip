@@ -1,0 +1,247 @@
+// Checks and times trk_span_kernel (gpsmi_trk_span.h) on fabricated descriptors, next to
+// trk_stream_mfma_kernel<4> on the same data: both against a float64 reference kernel, then
+// HIP-event times of back-to-back launches.  Tuning aid only (not part of the library).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Igps-sdr-receiver_amd/csrc \
+//         tools/probe/span_prof.hip gps-sdr-receiver_amd/csrc/gpsmi_core.hip \
+//         gps-sdr-receiver_amd/csrc/gpsmi_acq.hip -o tools/probe/span_prof
+//   tools/probe/span_prof [blocks = 1024]
+// (-DGPSMI_SP_PROF: per-wave cycle stamps instead of the timing runs)
+#include "../../gps-sdr-receiver_amd/csrc/gpsmi_trk.hip"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+
+using namespace gpsmi;
+
+// naive reference of partial[(b, c, o)], o = q + 1: window q = positions m >= d of row q plus
+// m < d of row q + 1 of  replica[(m - d) mod CS] x[r][m] exp(-j (ph + om (r CS + m + 1) / fs))
+__global__ void ref_kernel(const float2* iq, const JobMid* mid, const float* code2, int nch,
+                           int nblocks, double* out) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= nblocks * nch * 33) return;
+    const int o = id % 33, c = (id / 33) % nch, b = id / (33 * nch), q = o - 1;
+    const JobMid m = mid[b * nch + c];
+    const int d = m.delay_used;
+    double re = 0, im = 0;
+    if (m.active)
+        for (int part = 0; part < 2; ++part) {
+            const int r = q + part;
+            if (r < 0 || r > 31) continue;
+            for (int p = part ? 0 : d; p < (part ? d : 2048); ++p) {
+                const float2 x = iq[(size_t)b * 65536 + r * 2048 + p];
+                const double cv = code2[m.prn * 4096 + ((p - d) & 2047)];
+                const double th = (double)m.ph + (double)m.om * (double)(r * 2048 + p + 1) / 2048000.0;
+                const double cs = cos(th), sn = -sin(th);
+                re += cv * (x.x * cs - x.y * sn);
+                im += cv * (x.x * sn + x.y * cs);
+            }
+        }
+    out[2 * id] = re; out[2 * id + 1] = im;
+}
+
+struct Bufs {
+    float2* iq; JobMid* mid; float* code2; float* code_eo; float2* partial; float* park; double* ref;
+};
+
+template <int DIAG>
+static void launch_span_diag(const Bufs& B, int nblocks, int nch) {
+    TrkParams P{};
+    P.cs = 2048; P.n_cyc = 32; P.nch = nch;
+    const int ng = (nch + kSpCh - 1) / kSpCh;
+    hipLaunchKernelGGL(trk_span_kernel<DIAG>, dim3(((nblocks + 7) / 8) * 8 * ng), dim3(512), 0, 0, B.iq, B.mid,
+                       B.code_eo, P, ng, nblocks, B.park, B.partial);
+}
+static void launch_span(const Bufs& B, int nblocks, int nch) {
+    TrkParams P{};
+    P.cs = 2048; P.n_cyc = 32; P.nch = nch;
+    const int ng = (nch + kSpCh - 1) / kSpCh;
+    hipLaunchKernelGGL(trk_span_kernel<0>, dim3(((nblocks + 7) / 8) * 8 * ng), dim3(512), 0, 0, B.iq, B.mid,
+                       B.code_eo, P, ng, nblocks, B.park, B.partial);
+}
+static void launch_mfma(const Bufs& B, int nblocks, int nch) {
+    TrkParams P{};
+    P.cs = 2048; P.n_cyc = 32; P.nch = nch;
+    const int ng = (nch + kMfCh - 1) / kMfCh;
+    hipLaunchKernelGGL(trk_stream_mfma_kernel<4>, dim3(((nblocks + 7) / 8) * 8 * ng), dim3(256), 0, 0, B.iq,
+                       B.mid, B.code2, P, ng, nblocks, B.partial);
+}
+
+template <class F>
+static void check(const char* name, F launch, const Bufs& B, int nblocks, int nch) {
+    const int n = nblocks * nch * 33;
+    hipLaunchKernelGGL(ref_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, B.iq, B.mid, B.code2, nch,
+                       nblocks, B.ref);
+    hipMemset(B.partial, 0xff, (size_t)n * 8);
+    launch(B, nblocks, nch);
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) { printf("%s: %s\n", name, hipGetErrorString(e)); exit(1); }
+    std::vector<double> r(2 * n); std::vector<float2> g(n);
+    hipMemcpy(r.data(), B.ref, (size_t)n * 16, hipMemcpyDeviceToHost);
+    hipMemcpy(g.data(), B.partial, (size_t)n * 8, hipMemcpyDeviceToHost);
+    std::vector<JobMid> mid((size_t)nblocks * nch);
+    hipMemcpy(mid.data(), B.mid, mid.size() * sizeof(JobMid), hipMemcpyDeviceToHost);
+    double worst = 0, scale = 0; int wi = 0, nbad = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!mid[i / 33].active) continue;
+        const double e2 = std::max(fabs(g[i].x - r[2 * i]), fabs(g[i].y - r[2 * i + 1]));
+        scale = std::max(scale, std::max(fabs(r[2 * i]), fabs(r[2 * i + 1])));
+        if (!(e2 <= worst)) { worst = e2; wi = i; }
+        if (!(e2 <= 1e-3)) ++nbad;
+    }
+    printf("check %-12s %4d blocks x %2d ch: max |kernel - reference| = %.3g (largest value %.3g), %d bad, "
+           "worst at block %d ch %d (delay %d) o %d: (%g, %g) vs (%g, %g)\n", name, nblocks, nch, worst,
+           scale, nbad, wi / (33 * nch), (wi / 33) % nch, mid[wi / 33].delay_used, wi % 33, g[wi].x, g[wi].y,
+           r[2 * wi], r[2 * wi + 1]);
+}
+
+template <class F>
+static void timeit(const char* name, F launch, const Bufs& B, int nblocks, int nch) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) launch(B, nblocks, nch);
+    float best = 1e9f, sum = 0;
+    const int reps = 5, per = 10;
+    for (int r = 0; r < reps; ++r) {
+        hipEventRecord(e0, 0);
+        for (int i = 0; i < per; ++i) launch(B, nblocks, nch);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= per;
+        best = std::min(best, ms); sum += ms;
+    }
+    const double gb = (double)nblocks * 65536 * 8 / 1e9;
+    printf("time  %-12s %4d blocks x %2d ch: %.4f ms mean, %.4f best of %d x %d back-to-back launches: "
+           "%.0f GB/s (%.1f %% of 8 TB/s)\n", name, nblocks, nch, sum / reps, best, reps, per,
+           gb / (sum / reps) * 1e3, gb / (sum / reps) * 1e3 / 80.0);
+}
+
+static void set_delays(Bufs& B, int nblocks, int nch, int mode) {
+    static const int edge[12] = {0, 1, 2, 127, 128, 129, 511, 512, 513, 1023, 2046, 2047};
+    std::vector<JobMid> mid((size_t)nblocks * nch);
+    for (int b = 0; b < nblocks; ++b)
+        for (int c = 0; c < nch; ++c) {
+            JobMid& m = mid[(size_t)b * nch + c];
+            m = JobMid{};
+            m.delay_used = mode == 0 ? (1137 * c + 11) % 2048
+                         : mode == 1 ? edge[(c + b) % 12]
+                         : mode == 2 ? (40 * c + 20 + b) % 2048          // all boundaries in one quarter
+                         : (int)(((unsigned)(b * 131 + c * 977) * 2654435761u) >> 21);
+            m.active = (mode == 3 && (b + c) % 7 == 0) ? 0 : 1;
+            m.prn = 2 + c;
+            m.om = 6.2831853f * (-4000.f + 700.f * c); m.ph = 0.1f * b + c;
+        }
+    hipMemcpy(B.mid, mid.data(), mid.size() * sizeof(JobMid), hipMemcpyHostToDevice);
+}
+
+#ifdef GPSMI_SP_PROF
+static void prof(const Bufs& B, int nblocks, int nch) {
+    const size_t nw = (size_t)((nblocks + 7) / 8) * 8 * 8;
+    unsigned long long* d; hipMalloc((void**)&d, nw * 32);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_sp_prof), &d, sizeof(d));
+    unsigned long long zero = 0;
+    for (int it = 0; it < 3; ++it) {
+        hipMemset(d, 0, nw * 32);
+        hipMemcpyToSymbol(HIP_SYMBOL(g_sp_wait), &zero, 8);
+        launch_span(B, nblocks, nch);
+        hipDeviceSynchronize();
+    }
+    std::vector<unsigned long long> r(nw * 4);
+    hipMemcpy(r.data(), d, nw * 32, hipMemcpyDeviceToHost);
+    unsigned long long wait; hipMemcpyFromSymbol(&wait, HIP_SYMBOL(g_sp_wait), 8);
+    double loop = 0, bar = 0, comb = 0; unsigned long long tmin = ~0ull, tmax = 0; size_t n = 0;
+    std::vector<unsigned long long> starts;
+    for (size_t w = 0; w < nw; ++w) {
+        const unsigned long long* o = &r[w * 4];
+        if (!o[3]) continue;
+        loop += o[1] - o[0]; bar += o[2] - o[1]; comb += o[3] - o[2]; ++n;
+        tmin = std::min(tmin, o[0]); tmax = std::max(tmax, o[3]);
+        starts.push_back(o[0]);
+    }
+    std::sort(starts.begin(), starts.end());
+    printf("prof: %zu waves, first stamp -> last stamp %llu ticks; per wave: set-up + loop %.0f, to barrier %.0f, "
+           "combine %.0f; vmcnt wait at tile tops %.0f per wave (%.0f per tile)\n", n, tmax - tmin, loop / n,
+           bar / n, comb / n, (double)wait / n, (double)wait / n / 8);
+    printf("      wave starts (ticks after the first): 25%% %llu, 50%% %llu, 75%% %llu, last %llu\n",
+           starts[n / 4] - tmin, starts[n / 2] - tmin, starts[3 * n / 4] - tmin, starts[n - 1] - tmin);
+    hipFree(d);
+}
+#endif
+
+int main(int argc, char** argv) {
+    const int nblocks = argc > 1 ? atoi(argv[1]) : 1024, nch = 12;
+    const size_t blk = (size_t)2048 * 32;
+    Bufs B{};
+    hipMalloc((void**)&B.iq, nblocks * blk * sizeof(float2));
+    {
+        std::vector<float2> h(blk * 16);
+        unsigned s = 12345;
+        for (auto& v : h) {
+            s = s * 1664525u + 1013904223u; v.x = ((int)(s >> 16) % 256 - 128) / 512.f;
+            s = s * 1664525u + 1013904223u; v.y = ((int)(s >> 16) % 256 - 128) / 512.f;
+        }
+        for (int b = 0; b < nblocks; b += 16)
+            hipMemcpy(B.iq + b * blk, h.data(), std::min(16, nblocks - b) * blk * sizeof(float2),
+                      hipMemcpyHostToDevice);
+    }
+    hipMalloc((void**)&B.mid, (size_t)nblocks * nch * sizeof(JobMid));
+    // replica: doubled table [prn][2][2048] for the old kernel and the reference, parity planes
+    // [prn][e][2048] (entry s = code[2 (s mod 1024) + e]) for the span kernel
+    std::vector<float> code2((size_t)(GPSMI_MAX_PRN + 1) * 4096), eo(code2.size());
+    for (int p = 0; p <= GPSMI_MAX_PRN; ++p)
+        for (int i = 0; i < 2048; ++i) {
+            const float v = p == 0 ? 0.f : ((((unsigned)(p * 2048 + i) * 2654435761u) >> 13) & 1 ? 1.f : -0.75f);
+            code2[(size_t)p * 4096 + i] = code2[(size_t)p * 4096 + 2048 + i] = v;
+        }
+    for (int p = 0; p <= GPSMI_MAX_PRN; ++p)
+        for (int e = 0; e < 2; ++e)
+            for (int s = 0; s < 2048; ++s)
+                eo[(size_t)p * 4096 + e * 2048 + s] = code2[(size_t)p * 4096 + 2 * (s % 1024) + e];
+    hipMalloc((void**)&B.code2, code2.size() * 4);
+    hipMemcpy(B.code2, code2.data(), code2.size() * 4, hipMemcpyHostToDevice);
+    hipMalloc((void**)&B.code_eo, eo.size() * 4);
+    hipMemcpy(B.code_eo, eo.data(), eo.size() * 4, hipMemcpyHostToDevice);
+    hipMalloc((void**)&B.partial, (size_t)nblocks * nch * 33 * sizeof(float2));
+    hipMalloc((void**)&B.park, (size_t)(((nblocks + 7) / 8) * 8) * 8 * kSpParkFloats * sizeof(float));
+    hipMalloc((void**)&B.ref, (size_t)64 * nch * 33 * 16);
+
+    const int ncheck = std::min(nblocks, 24);
+    for (int mode = 0; mode < 4; ++mode) {
+        set_delays(B, nblocks, nch, mode);
+        printf("-- delays: %s\n", mode == 0 ? "spread" : mode == 1 ? "edges" : mode == 2 ? "one quarter" : "random, some closed");
+        check("mfma<4>", launch_mfma, B, ncheck, nch);
+        check("span", launch_span, B, ncheck, nch);
+        if (mode == 3) check("span 5ch", launch_span, B, ncheck, 5);
+    }
+#ifdef GPSMI_SP_PROF
+    set_delays(B, nblocks, nch, 0);
+    prof(B, nblocks, nch);
+    return 0;
+#endif
+    for (int mode : {0, 2}) {
+        set_delays(B, nblocks, nch, mode);
+        printf("-- delays: %s\n", mode == 0 ? "spread" : "one quarter");
+        timeit("mfma<4>", launch_mfma, B, nblocks, nch);
+        timeit("span", launch_span, B, nblocks, nch);
+        timeit("mfma<4>", launch_mfma, B, nblocks, nch);
+        timeit("span", launch_span, B, nblocks, nch);
+    }
+    set_delays(B, nblocks, nch, 0);
+    printf("-- diagnostics (delays spread): 1 no MFMAs, 2 no row loads after the first tile, 4 no barrier / combine\n");
+    timeit("span diag 4", launch_span_diag<4>, B, nblocks, nch);
+    timeit("span diag 1", launch_span_diag<1>, B, nblocks, nch);
+    timeit("span diag 2", launch_span_diag<2>, B, nblocks, nch);
+    timeit("span diag 5", launch_span_diag<5>, B, nblocks, nch);
+    timeit("span diag 6", launch_span_diag<6>, B, nblocks, nch);
+    timeit("span diag 7", launch_span_diag<7>, B, nblocks, nch);
+    {   // no boundary anywhere: every delay 0
+        std::vector<JobMid> mid((size_t)nblocks * nch);
+        hipMemcpy(mid.data(), B.mid, mid.size() * sizeof(JobMid), hipMemcpyDeviceToHost);
+        for (auto& m : mid) m.delay_used = 0;
+        hipMemcpy(B.mid, mid.data(), mid.size() * sizeof(JobMid), hipMemcpyHostToDevice);
+        printf("-- every delay 0 (no boundary tiles)\n");
+        timeit("span", launch_span, B, nblocks, nch);
+        timeit("mfma<4>", launch_mfma, B, nblocks, nch);
+    }
+    return 0;
+}
