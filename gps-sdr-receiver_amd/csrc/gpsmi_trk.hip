@@ -109,11 +109,11 @@ __device__ inline double fit_code_phase(double lo, double pk, double hi, int mx)
 #include "gpsmi_trk_stream.h"
 #include "gpsmi_trk_stream_lds.h"
 #include "gpsmi_trk_stream_mfma.h"
-#include "gpsmi_trk_span.h"
 #include "gpsmi_trk_corr.h"
 #include "gpsmi_bigfft.h"
 #include "gpsmi_trk_general.h"
 #pragma clang fp contract(off)
+#include "gpsmi_trk_span.h"
 
 namespace gpsmi {
 
@@ -144,8 +144,10 @@ __device__ inline float np_sum_f32(const float* a, int n) {
 __global__ __launch_bounds__(256) void trk_epilogue_kernel(
     const gpsmi_trk_state* __restrict__ st_in, gpsmi_trk_state* __restrict__ st_out,
     const JobMid* __restrict__ mid, const float2* __restrict__ partial, TrkParams P,
-    int njobs, gpsmi_trk_out* __restrict__ out) {
+    int njobs, gpsmi_trk_out* __restrict__ out, const float* __restrict__ spanout, int ng_span) {
     __shared__ float s_mag[4][40], s_dev[4][40], s_real[4][40], s_df[4][GPSMI_MAX_DF];
+    __shared__ float s_hi[4][64], s_lo[4][64];
+    __shared__ float2 s_S[4][GPSMI_MAX_DUMPS];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int job = blockIdx.x * 4 + wave;
     if (job >= njobs) return;
@@ -168,6 +170,11 @@ __global__ __launch_bounds__(256) void trk_epilogue_kernel(
     const int d = mid[job].delay_used;
     const int cs = P.cs, nc = P.n_cyc;
     const float2* S = partial + (size_t)job * (nc + 1);   // S[0] head, S[q+1] window q, S[nc] tail
+    if (spanout) {          // single-block form of the span correlator: its raw sums are added up here
+        span_collect(spanout, ng_span, job / P.nch, job % P.nch, d, mid[job].om, lane, s_hi[wave],
+                     s_lo[wave], s_S[wave]);
+        S = s_S[wave];
+    }
     // scalar state (same address in every lane: one broadcast load each)
     const int nps = si.nps, df_len = si.df_len, was_locked = si.phase_locked;
     const float freq0 = si.freq, phase0 = si.phase, omega0 = si.omega0;
@@ -326,9 +333,13 @@ struct gpsmi_trk {
     // code_samples != 2048: time-domain correlation + chunked correlator
     bool general = false;
     int stream_j = 8;                // code positions per lane of the correlator (8 or 4)
-    int mfma = 0;                    // MFMA correlator (default where it applies): 3 = four waves per
-                                     // workgroup, three workgroups per CU; 1 = eight waves
+    int mfma = 0;                    // MFMA correlator (default where it applies): 4 = span form
+                                     // (gpsmi_trk_span.h); 3 = 32x32x2 form, four waves per workgroup,
+                                     // three workgroups per CU; 1 = the same with eight waves
     float* d_code2 = nullptr;        // [GPSMI_MAX_PRN + 1][2 cs]: replica twice (no index wrap)
+    float* d_code_eo = nullptr;      // [GPSMI_MAX_PRN + 1][2][cs]: replica split by index parity, each
+                                     // plane twice (span form)
+    float* d_spanout = nullptr;      // raw span sums of the single-block form, kSpanUnitsMax units
     int nchunks = 1;                 // spans of 256 * stream_j positions per code period
     float2* d_fold = nullptr; float* d_mag = nullptr; DirStats* d_stats = nullptr;
     int* d_xsel = nullptr; int* d_rsel = nullptr; float2* d_partial_g = nullptr;
@@ -336,6 +347,8 @@ struct gpsmi_trk {
     float2* d_twN = nullptr; float2* d_RS = nullptr; float2* d_S = nullptr;
     TrkParams P;
 };
+
+constexpr int kSpanUnitsMax = 16;    // (block, channel group) pairs the single-block span form serves
 
 static int trk_reserve(gpsmi_trk* h, size_t njobs) {
     if (njobs <= h->njobs_cap) return GPSMI_OK;
@@ -380,6 +393,10 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const float2* d_iq,
     const int nblocks = njobs / nch;
     const int ngroups = (nch + kGroupCh - 1) / kGroupCh;
     const dim3 sgrid(((nblocks + 7) / 8) * 8 * ngroups);
+    // a launch too small to fill the CUs with whole blocks (the closed loop): every span of
+    // a block is a wave of its own; same bits as the batch form (gpsmi_trk_span.h)
+    const int ng_span = (nch + kSpCh - 1) / kSpCh;
+    const bool span_single = h->mfma == 4 && nblocks * ng_span <= kSpanUnitsMax;
     // ---- code-phase correlation
     if (h->general) {
         const int cs = P.cs;
@@ -420,7 +437,13 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const float2* d_iq,
     if (h->mfma) {                         // the correlator on the matrix pipe
         const int ng12 = (nch + kMfCh - 1) / kMfCh;
         const dim3 mgrid(((nblocks + 7) / 8) * 8 * ng12);
-        if (h->mfma != 1)
+        if (h->mfma == 4 && span_single)
+            hipLaunchKernelGGL(trk_span_single_kernel, dim3(nblocks * ng12 * 8), dim3(256), 0, h->stream,
+                               d_iq, h->d_mid, h->d_code_eo, P, ng12, nblocks, h->d_spanout);
+        else if (h->mfma == 4)
+            hipLaunchKernelGGL(trk_span_kernel<0>, mgrid, dim3(256), 0, h->stream, d_iq, h->d_mid,
+                               h->d_code_eo, P, ng12, nblocks, h->d_partial);
+        else if (h->mfma != 1)
             hipLaunchKernelGGL(trk_stream_mfma_kernel<4>, mgrid, dim3(256), 0, h->stream, d_iq,
                                h->d_mid, h->d_code2, P, ng12, nblocks, h->d_partial);
         else
@@ -473,7 +496,8 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const float2* d_iq,
     }
     if (timed) GPSMI_HIP(hipEventRecord(sl.ev[2], h->stream));
     hipLaunchKernelGGL(trk_epilogue_kernel, dim3((njobs + 3) / 4), dim3(256), 0, h->stream, st_in,
-                       st_out, h->d_mid, h->d_partial, P, njobs, sl.d_out);
+                       st_out, h->d_mid, h->d_partial, P, njobs, sl.d_out,
+                       span_single ? h->d_spanout : (const float*)nullptr, ng_span);
     GPSMI_HIP(hipGetLastError());
     if (timed) GPSMI_HIP(hipEventRecord(sl.ev[3], h->stream));
     return GPSMI_OK;
@@ -572,15 +596,19 @@ int gpsmi_trk_create(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk** out) {
     GPSMI_HIP(hipMemset(h->d_code, 0, code_bytes));          // slot 0: closed channels
     {
         const char* mf = getenv("GPSMI_STREAM_MFMA");
-        // default for CS = 2048, N_CYC = 32: the MFMA kernel with four waves per workgroup;
-        // GPSMI_STREAM_MFMA=1 selects its eight-wave form (shorter latency for a single block,
-        // lower throughput for a batch), =0 the vector kernel.  One form per handle: the closed
-        // loop and the replay of a handle sum in the same order (bytewise equal results).
-        h->mfma = (!h->general && cfg->n_cyc == 32 && !(mf && atoi(mf) == 0)) ? (mf ? atoi(mf) : 3) : 0;
+        // default for CS = 2048, N_CYC = 32: the span form of the MFMA correlator;
+        // GPSMI_STREAM_MFMA=3 selects the 32x32x2 form with four waves per workgroup, =1 its
+        // eight-wave form, =0 the vector kernel.  One form per handle: the closed loop and the
+        // replay of a handle sum in the same order (bytewise equal results).
+        h->mfma = (!h->general && cfg->n_cyc == 32 && !(mf && atoi(mf) == 0)) ? (mf ? atoi(mf) : 4) : 0;
         if (h->mfma) {
             const size_t b2 = (size_t)(GPSMI_MAX_PRN + 1) * 2 * kFftN * sizeof(float);
             GPSMI_HIP(hipMalloc((void**)&h->d_code2, b2));
             GPSMI_HIP(hipMemset(h->d_code2, 0, b2));
+            GPSMI_HIP(hipMalloc((void**)&h->d_code_eo, b2));
+            GPSMI_HIP(hipMemset(h->d_code_eo, 0, b2));
+            GPSMI_HIP(hipMalloc((void**)&h->d_spanout,
+                                (size_t)kSpanUnitsMax * kSpUnitOutFloats * sizeof(float)));
         }
     }
     if (h->general) {
@@ -627,7 +655,7 @@ int gpsmi_trk_destroy(gpsmi_trk* h) {
                     h->d_tab_out, h->d_forced, h->d_mid, h->d_partial, h->slot[0].d_out,
                     h->slot[1].d_out, h->d_fold,
                     h->d_mag, h->d_stats, h->d_xsel, h->d_rsel, h->d_partial_g, h->d_twN, h->d_RS,
-                    h->d_S, h->d_code2};
+                    h->d_S, h->d_code2, h->d_code_eo, h->d_spanout};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto& sl : h->slot) {
@@ -655,6 +683,11 @@ int gpsmi_trk_set_replica(gpsmi_trk* h, int prn, const float* replica, const flo
                             hipMemcpyHostToDevice));
         GPSMI_HIP(hipMemcpy(h->d_code2 + (size_t)prn * 2 * kFftN + kFftN, replica,
                             kFftN * sizeof(float), hipMemcpyHostToDevice));
+        std::vector<float> eo(2 * kFftN);          // plane e, entry s = replica[2 (s mod 1024) + e]
+        for (int e = 0; e < 2; ++e)
+            for (int i = 0; i < kFftN; ++i) eo[e * kFftN + i] = replica[2 * (i % (kFftN / 2)) + e];
+        GPSMI_HIP(hipMemcpy(h->d_code_eo + (size_t)prn * 2 * kFftN, eo.data(), eo.size() * sizeof(float),
+                            hipMemcpyHostToDevice));
     }
     if (!h->general)                       // the other path needs no 2048-point spectrum
         GPSMI_HIP(hipMemcpy(h->d_rep + (size_t)prn * kFftN, spectrum, kFftN * sizeof(float2),

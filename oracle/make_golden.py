@@ -15,6 +15,7 @@ detected.
     python oracle/make_golden.py hirate     # CODE_SAMPLES=16368, N_CYC=8
     python oracle/make_golden.py navbits    # Subframe / evalGpsBits on constructed frames
     python oracle/make_golden.py position   # SatOrbit / SatPos / leastSquaresPos4 / ecefToGeo
+    python oracle/make_golden.py resweep    # SatStream.initSweep / sweepFrequency / restoreFreq
 
 The reference binds its configuration at import time (``from gpsglob import``),
 so each configuration runs in its own interpreter.
@@ -452,17 +453,75 @@ def run_position():
           float(np.linalg.norm(last - truth)), 'm')
 
 
+RESWEEP_CASES = (
+    # name, PRN, Doppler and delay the channel is opened with, tracking blocks before the
+    # trigger, blocks after it.  PRN 21 sits at +3200 Hz: the 40 bins of the first call
+    # (-5000 .. +2800 Hz) miss it and the second call finds it; PRN 4 (-2000 Hz) is found in
+    # the first call; PRN 3 is not in the scene: two calls run off to +10800 Hz, restoreFreq.
+    ('two_calls', 21, 3200.0, 1458, 3, 7),
+    ('one_call', 4, -2000.0, 143, 3, 6),
+    ('no_signal', 3, 1234.5, 100, 3, 6),
+)
+
+
+def run_resweep():
+    """Per-channel re-acquisition of the real gpslib.SatStream (initSweep :1110-1116,
+    the sweep branch of process :1153-1173, sweepFrequency / getCorrMax :1350-1380,
+    restoreFreq :1118-1120) on the default fixture scene -> ref_resweep.npz.  The sweep is
+    triggered through process(..., sweep=True), the reference's own argument."""
+    import numpy as np
+    gpsglob, gpslib, gpsrecv = _import_reference(2048, 32)
+    ngps = 2048 * 32
+    scene = scene_for('default')
+    first = 5
+    out = {'numpy': np.__version__, 'first_block': first}
+    keys = ('sweep', 'freq', 'freq_is_f32', 'max_corr', 'delay', 'code_phase', 'corr_q',
+            'corr_l', 'phase', 'locked', 'df_len', 'n_frames', 'swp_reported')
+    for name, sv, f0, d0, n_before, n_after in RESWEEP_CASES:
+        nb = n_before + n_after
+        ss = gpslib.SatStream(sv, f0, delay=d0, itSweep=gpsglob.IT_SWEEP,
+                              corrMin=gpsglob.CORR_MIN, corrAvg=gpsglob.CORR_AVG,
+                              sweepCorrAvg=gpsglob.SWEEP_CORR_AVG)
+        rec = {k: np.zeros(nb) for k in keys}
+        for i in range(nb):
+            b = first + i
+            blk = scene.block(b)
+            smp_time = np.int64((b + 1) * ngps)
+            sw, fl, co_ph, (cq, cl) = ss.process(blk, smp_time, sweep=(i == n_before))
+            vals = dict(sweep=sw, freq=float(ss.FREQ),
+                        freq_is_f32=isinstance(ss.FREQ, np.float32), max_corr=ss.MAX_CORR,
+                        delay=ss.DELAY, code_phase=co_ph, corr_q=cq, corr_l=cl,
+                        phase=float(ss.PHASE), locked=ss.PHASE_LOCKED, df_len=len(ss.DF),
+                        n_frames=len(fl),
+                        swp_reported=(fl[0]['SWP'] if fl else -1))
+            for k, v in vals.items():
+                rec[k][i] = v
+        for k, v in rec.items():
+            out[f'{name}_{k}'] = v
+        out[f'{name}_init'] = np.array([sv, f0, d0, n_before, n_after], dtype=np.float64)
+    os.makedirs(GOLD, exist_ok=True)
+    path = os.path.join(GOLD, 'ref_resweep.npz')
+    np.savez_compressed(path, **out)
+    for name, *_ in RESWEEP_CASES:
+        print(name, 'sweep', out[f'{name}_sweep'].astype(int).tolist(), 'freq',
+              out[f'{name}_freq'].tolist(), 'delay', out[f'{name}_delay'].astype(int).tolist())
+    print(path, os.path.getsize(path), 'bytes')
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1:
         if sys.argv[1] == 'navbits':
             run_navbits()
         elif sys.argv[1] == 'position':
             run_position()
+        elif sys.argv[1] == 'resweep':
+            run_resweep()
         else:
             run(sys.argv[1])
     else:
         subprocess.check_call([sys.executable, os.path.abspath(__file__), 'navbits'])
         subprocess.check_call([sys.executable, os.path.abspath(__file__), 'position'])
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), 'resweep'])
         for cfg in ('default', 'hirate'):
             subprocess.check_call([sys.executable, os.path.abspath(__file__),
                                    cfg])

@@ -115,6 +115,38 @@ def test_satstream_process(cfg, golden_default, golden_hirate):
                 assert float(v) == g['trk_' + k][c, i], (c, i, k)
 
 
+RESWEEP_CASES = ('two_calls', 'one_call', 'no_signal')
+
+
+@pytest.mark.parametrize('case', RESWEEP_CASES)
+def test_resweep_matches_reference(case):
+    """Per-channel re-acquisition (gpslib.py:1110-1120 initSweep / restoreFreq, :1153-1173
+    the sweep branch of process, :1350-1380 getCorrMax / sweepFrequency) against what the
+    real SatStream returned (tests/golden/ref_resweep.npz): a hit in the second 40-bin
+    call, a hit in the first, and the no-signal run-off to +10800 Hz with restoreFreq."""
+    from conftest import load_golden
+    g = load_golden('ref_resweep.npz')
+    sv, f0, d0, n_before, n_after = g[case + '_init']
+    p = orc.Params()
+    nb = int(n_before + n_after)
+    first = int(g['first_block'])
+    blocks = scene_blocks('default', first, nb)
+    ss = orc.SatStream(int(sv), float(f0), p, delay=int(d0))
+    for i in range(nb):
+        smp = np.int64((first + i + 1) * p.ngps)
+        sw, fl, co_ph, (cq, cl) = ss.process(blocks[i], smp, sweep=(i == int(n_before)))
+        got = dict(sweep=sw, freq=float(ss.freq), freq_is_f32=isinstance(ss.freq, np.float32),
+                   max_corr=ss.max_corr, delay=ss.delay, code_phase=co_ph, corr_q=cq,
+                   corr_l=cl, phase=float(ss.phase), locked=ss.phase_locked,
+                   df_len=len(ss.df), n_frames=len(fl),
+                   swp_reported=(fl[0]['SWP'] if fl else -1))
+        for k, v in got.items():
+            assert float(v) == g[f'{case}_{k}'][i], (case, i, k)
+    # the cases really are what their names say
+    sweeps = g[case + '_sweep'].astype(int).tolist()
+    assert sum(sweeps) == (0 if case == 'one_call' else 1)
+
+
 def test_fit_code_phase_wraps():
     """gpslib.py:1268-1290 circular neighbours at both ends."""
     corr = np.full(16, 1.0)

@@ -41,7 +41,7 @@ __global__ void ref_kernel(const float2* iq, const JobMid* mid, const float* cod
 }
 
 struct Bufs {
-    float2* iq; JobMid* mid; float* code2; float* code_eo; float2* partial; float* park; double* ref;
+    float2* iq; JobMid* mid; float* code2; float* code_eo; float2* partial; double* ref;
 };
 
 template <int DIAG>
@@ -49,15 +49,15 @@ static void launch_span_diag(const Bufs& B, int nblocks, int nch) {
     TrkParams P{};
     P.cs = 2048; P.n_cyc = 32; P.nch = nch;
     const int ng = (nch + kSpCh - 1) / kSpCh;
-    hipLaunchKernelGGL(trk_span_kernel<DIAG>, dim3(((nblocks + 7) / 8) * 8 * ng), dim3(512), 0, 0, B.iq, B.mid,
-                       B.code_eo, P, ng, nblocks, B.park, B.partial);
+    hipLaunchKernelGGL(trk_span_kernel<DIAG>, dim3(((nblocks + 7) / 8) * 8 * ng), dim3(256), 0, 0, B.iq, B.mid,
+                       B.code_eo, P, ng, nblocks, B.partial);
 }
 static void launch_span(const Bufs& B, int nblocks, int nch) {
     TrkParams P{};
     P.cs = 2048; P.n_cyc = 32; P.nch = nch;
     const int ng = (nch + kSpCh - 1) / kSpCh;
-    hipLaunchKernelGGL(trk_span_kernel<0>, dim3(((nblocks + 7) / 8) * 8 * ng), dim3(512), 0, 0, B.iq, B.mid,
-                       B.code_eo, P, ng, nblocks, B.park, B.partial);
+    hipLaunchKernelGGL(trk_span_kernel<0>, dim3(((nblocks + 7) / 8) * 8 * ng), dim3(256), 0, 0, B.iq, B.mid,
+                       B.code_eo, P, ng, nblocks, B.partial);
 }
 static void launch_mfma(const Bufs& B, int nblocks, int nch) {
     TrkParams P{};
@@ -136,19 +136,18 @@ static void set_delays(Bufs& B, int nblocks, int nch, int mode) {
 
 #ifdef GPSMI_SP_PROF
 static void prof(const Bufs& B, int nblocks, int nch) {
-    const size_t nw = (size_t)((nblocks + 7) / 8) * 8 * 8;
+    const size_t nw = (size_t)((nblocks + 7) / 8) * 8 * 4;
     unsigned long long* d; hipMalloc((void**)&d, nw * 32);
     hipMemcpyToSymbol(HIP_SYMBOL(g_sp_prof), &d, sizeof(d));
-    unsigned long long zero = 0;
+    unsigned long long z4[4] = {0, 0, 0, 0};
     for (int it = 0; it < 3; ++it) {
         hipMemset(d, 0, nw * 32);
-        hipMemcpyToSymbol(HIP_SYMBOL(g_sp_wait), &zero, 8);
+        hipMemcpyToSymbol(HIP_SYMBOL(g_sp_acc), z4, 32);
         launch_span(B, nblocks, nch);
         hipDeviceSynchronize();
     }
     std::vector<unsigned long long> r(nw * 4);
     hipMemcpy(r.data(), d, nw * 32, hipMemcpyDeviceToHost);
-    unsigned long long wait; hipMemcpyFromSymbol(&wait, HIP_SYMBOL(g_sp_wait), 8);
     double loop = 0, bar = 0, comb = 0; unsigned long long tmin = ~0ull, tmax = 0; size_t n = 0;
     std::vector<unsigned long long> starts;
     for (size_t w = 0; w < nw; ++w) {
@@ -159,11 +158,11 @@ static void prof(const Bufs& B, int nblocks, int nch) {
         starts.push_back(o[0]);
     }
     std::sort(starts.begin(), starts.end());
-    printf("prof: %zu waves, first stamp -> last stamp %llu ticks; per wave: set-up + loop %.0f, to barrier %.0f, "
-           "combine %.0f; vmcnt wait at tile tops %.0f per wave (%.0f per tile)\n", n, tmax - tmin, loop / n,
-           bar / n, comb / n, (double)wait / n, (double)wait / n / 8);
-    printf("      wave starts (ticks after the first): 25%% %llu, 50%% %llu, 75%% %llu, last %llu\n",
-           starts[n / 4] - tmin, starts[n / 2] - tmin, starts[3 * n / 4] - tmin, starts[n - 1] - tmin);
+    hipMemcpyFromSymbol(z4, HIP_SYMBOL(g_sp_acc), 32);
+    printf("prof: %zu waves; per wave: set-up + loop %.0f, to barrier %.0f, combine %.0f ticks\n", n, loop / n,
+           bar / n, comb / n);
+    printf("      of the first: set-up %.0f, wait for the first rows %.0f, the 8 tile tops (stores to LDS, "
+           "next loads) %.0f\n", (double)(z4[2] - z4[3]) / n, (double)z4[0] / n, (double)z4[1] / n);
     hipFree(d);
 }
 #endif
@@ -202,7 +201,6 @@ int main(int argc, char** argv) {
     hipMalloc((void**)&B.code_eo, eo.size() * 4);
     hipMemcpy(B.code_eo, eo.data(), eo.size() * 4, hipMemcpyHostToDevice);
     hipMalloc((void**)&B.partial, (size_t)nblocks * nch * 33 * sizeof(float2));
-    hipMalloc((void**)&B.park, (size_t)(((nblocks + 7) / 8) * 8) * 8 * kSpParkFloats * sizeof(float));
     hipMalloc((void**)&B.ref, (size_t)64 * nch * 33 * 16);
 
     const int ncheck = std::min(nblocks, 24);
