@@ -395,7 +395,7 @@ def main():
             },
             'x_realtime': round(value / 2.048, 1),
             'roofline': {
-                'bound': 'hbm', 'kernel': 'trk_stream_mfma_kernel',
+                'bound': 'hbm', 'kernel': 'trk_span_kernel',
                 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
                 'traffic': pmc_traffic() if nb == 1024 else None,

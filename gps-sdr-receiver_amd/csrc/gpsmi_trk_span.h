@@ -7,13 +7,14 @@
 //       positions; 256-byte segments top out at 5.2 TB/s, 512-byte ones reach 5.7-6.0,
 //       tools/probe/tile_read.hip),
 //   (2) a batch of 1024 blocks is two full rounds of workgroups (two workgroups of four
-//       waves per CU, 18 KiB of LDS per wave) with no one-wave-per-SIMD tail,
+//       waves per CU, 18 KiB of LDS per wave) with no one-wave-per-SIMD tail, and the waves
+//       of a workgroup never wait for each other (no barrier: each writes its own sums),
 //   (3) the order of the float32 sums is defined by the DATA, not by the launch: a block
 //       is cut into 32 SPANS of 64 positions; a span is summed position by position, the
 //       spans of a quarter (512 positions) are added in order, then the four quarters.
 //       Any assignment of spans to waves that follows this order gives the same bits:
 //       the batch form gives a wave a quarter (eight spans), the single-block form gives
-//       every span its own wave (32 waves on 8 workgroups instead of 4 waves on one CU).
+//       every span its own wave (32 waves on up to 32 CUs instead of 4 waves on one).
 //
 //   v_mfma_f32_16x16x4_f32, D[16 x 16] += A[16 x 4] B[4 x 16] for one PAIR of positions:
 //     M = 16 code periods (two M tiles = the 32 rows of the block),
@@ -59,13 +60,6 @@ constexpr int kSpCodeFloats = kSpCh * 2 * kSpCodePitch;
 constexpr int kSpWaveFloats = kSpTileFloats + kSpCodeFloats;     // 4640 floats = 18,560 B per wave
 constexpr int kSpInf = 1 << 20;
 
-#ifdef GPSMI_SP_PROF       // tools/probe/span_prof.hip only: per-wave cycle stamps
-__device__ unsigned long long* g_sp_prof;
-__device__ unsigned long long g_sp_acc[4];     // set-up, tile tops, wait for the first rows
-#define SP_STAMP() clock64()
-#else
-#define SP_STAMP() 0ull
-#endif
 
 typedef float sp4 __attribute__((ext_vector_type(4)));
 typedef float sp2 __attribute__((ext_vector_type(2)));
@@ -152,7 +146,8 @@ template <int NSPANS, int DIAG = 0>
 __device__ __forceinline__ void span_wave(const float2* __restrict__ blk, float* tl, float* cd,
                                           const JobMid* __restrict__ midrow, int nch_g,
                                           const float* __restrict__ code_eo, int pos0, int lane,
-                                          sp4 (&tot)[2][2], sp4 (&lo_fin)[2][2], bool (&all_lo)[2]) {
+                                          sp4 (&tot)[2][2], sp4 (&lo_fin)[2][2], bool (&all_lo)[2],
+                                          int (&pb)[2]) {
     constexpr int CS = kFftN, NC = 32;
     const int j = lane & 15, k = lane >> 4, pi = k >> 1, kap = k & 1, part = j & 1;
     const int q0 = pos0 & ~(kSpQuarter - 1);                      // start of the quarter
@@ -187,7 +182,7 @@ __device__ __forceinline__ void span_wave(const float2* __restrict__ blk, float*
     const float inv_fs = 1.0f / (1000.0f * (float)CS);
     const float sx = ((kap == 0) == (part == 0)) ? 1.f : 0.f;          // (0,re) and (1,im): +z.x
     const float sy = (sx != 0.f) ? 0.f : (part == 0 ? -1.f : 1.f);     // (1,re): -z.y, (0,im): +z.y
-    int pb[2];                        // boundary relative to the quarter start, kSpInf if outside (0, 512)
+    // pb: boundary relative to the quarter start, kSpInf if outside (0, 512)
     const float* crow[2];             // LDS: the lane's replica rows of the current window
     sp2 u2[2], dl2[2], nk;
     float nkv[2];
@@ -281,17 +276,8 @@ __device__ __forceinline__ void span_wave(const float2* __restrict__ blk, float*
     const float* ap0 = tl + (lane & 15) * kSpRowDw + k;              // lane = (row, k), rows 0 .. 15
     const float* ap1 = ap0 + 16 * kSpRowDw;                          // rows 16 .. 31
 
-#ifdef GPSMI_SP_PROF
-    const unsigned long long tsa = clock64();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned long long tsb = clock64();
-    unsigned long long ts_top = 0;
-#endif
 #pragma unroll 1
     for (int tix = 0; tix < kTiles; ++tix) {
-#ifdef GPSMI_SP_PROF
-        const unsigned long long tt0 = clock64();
-#endif
         // the tile that waited in registers goes to LDS (the reads of the previous one are
         // behind us: LDS serves a wave in order), then the tile after it is requested
         // (unconditional: past the end the last tile is fetched again and never used)
@@ -300,9 +286,6 @@ __device__ __forceinline__ void span_wave(const float2* __restrict__ blk, float*
         load_code(2 * tix + 1);
         if (!(DIAG & 2)) load_tile(tix + 1 < kTiles ? tix + 1 : kTiles - 1);
         __builtin_amdgcn_sched_barrier(0);
-#ifdef GPSMI_SP_PROF
-        ts_top += clock64() - tt0;
-#endif
         const int tpos = rel0 + tix * kSpTile;                       // tile start within the quarter
 
         // operands of four pairs (eight positions): the lane's component of the samples of
@@ -414,79 +397,92 @@ __device__ __forceinline__ void span_wave(const float2* __restrict__ blk, float*
 #pragma unroll
             for (int n = 0; n < 2; ++n) tot[mt][n] = tot[mt][n] + acc[mt][n];
     }
-#ifdef GPSMI_SP_PROF
-    if (lane == 0) {
-        atomicAdd(&g_sp_acc[0], tsb - tsa);
-        atomicAdd(&g_sp_acc[1], ts_top);
-        atomicAdd(&g_sp_acc[2], tsa);       // (with ts0 subtracted by the caller: set-up)
-    }
-#endif
 }
 
-// what a range contributes to the two sides of the delay (all_lo: the whole QUARTER is lo)
-__device__ __forceinline__ void span_sides(const sp4& tot, const sp4& lo_fin, bool all_lo, sp4& w_hi,
-                                           sp4& w_lo) {
-    const sp4 z = sp4{0.f, 0.f, 0.f, 0.f};
-    w_hi = all_lo ? z : tot;
-    w_lo = all_lo ? tot : lo_fin;
-}
+// ---- the kernels.  18.1 KiB of LDS per wave = eight waves per CU.
+//   batch form:        range = quarter; the four quarters of a block are the four waves of
+//                      one workgroup (so the four 4 KiB pieces of every 16 KiB row are
+//                      requested together).  The waves leave their hi / lo row sums in LDS;
+//                      behind the one barrier of the kernel all threads add the quarters in
+//                      their fixed order and write partial[job][.] (3 KiB per block).
+//                      Measured instead, per 1024-block launch: the wave that arrives last
+//                      combines alone, the others exit without a barrier +6 us (the
+//                      workgroup's LDS is held until that wave is done); one-wave workgroups
+//                      that write 4 KiB records of raw sums +6 us, four-wave ones +9 us.
+//   single-block form: range = span, 32 one-wave workgroups per (block, channel group), for
+//                      a launch too small to fill the CUs with quarters (the closed loop).
+//                      A wave writes the raw sums of its span (tot always, lo_fin by the
+//                      lanes whose boundary lay inside it) to `rec`, 2048 floats per wave:
+//                        rec[unit = b * ngroups + g][span][tot | lo_fin][M tile][N tile][v][lane]
+//                      and span_collect (called by the epilogue kernel) adds the spans of a
+//                      block up in the order the batch form uses: same bits.
+constexpr int kSpRecFloats = 2 * 16 * 64;              // one wave's record
+constexpr int kSpLoOfs = 16 * 64;                      // lo_fin within it
 
-// ---- batch form: one workgroup = one block x up to 12 channels, four waves = the four
-// quarters; two workgroups per CU.  Output as trk_stream_mfma_kernel:
-// partial[job][q + 1] = U[q] hi[q] + U[q+1] lo[q+1].
-// (DIAG, probes only: 4 no barrier / combine)
-template <int DIAG = 0>
-__global__ __launch_bounds__(256, 2) void trk_span_kernel(
+template <int NSPANS, int WAVES, int DIAG = 0>
+__global__ __launch_bounds__(64 * WAVES, 2) void trk_span_kernel(
     const float2* __restrict__ iq, const JobMid* __restrict__ mid,
     const float* __restrict__ code_eo, TrkParams P, int ngroups, int nblocks,
-    float2* __restrict__ partial) {
+    float* __restrict__ rec, float2* __restrict__ partial) {
     constexpr int NC = 32, CS = kFftN;
-    __shared__ __attribute__((aligned(16))) float lds[4][kSpWaveFloats];
-    constexpr int kSumFloats = kSpCh * NC * 2;          // [channel][row][re, im]
-    static_assert(2 * kSumFloats <= kSpTileFloats, "row sums must fit the tile area");
-
-    [[maybe_unused]] const unsigned long long ts0 = SP_STAMP();
-#ifdef GPSMI_SP_PROF
-    if ((threadIdx.x & 63) == 0) atomicAdd(&g_sp_acc[3], ts0);
-#endif
-    const int wg = blockIdx.x;
-    const int xcd = wg & 7, slot = wg >> 3;
-    const int g = slot % ngroups;
-    const int b = (slot / ngroups) * 8 + xcd;
+    constexpr int kRanges = CS / (NSPANS * kSpTile);    // per block: 4 quarters or 32 spans
+    constexpr bool kWholeBlock = kRanges == WAVES;      // the workgroup holds all ranges of its block
+    static_assert(kRanges % WAVES == 0, "the waves of a workgroup share a block");
+    __shared__ __attribute__((aligned(16))) float lds[WAVES][kSpWaveFloats];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int widx = blockIdx.x * WAVES + wave;
+    const int unit = widx / kRanges, range = widx % kRanges;
+    const int g = unit % ngroups, b = unit / ngroups;
     if (b >= nblocks) return;
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const float2* blk = iq + (size_t)b * ((size_t)CS * NC);
-    const int nch_g = P.nch - g * kSpCh;
-    float* tl = &lds[wave][0];
-    float* cd = tl + kSpTileFloats;
-
-    // ---- for the combine step at the end: which partial[q + 1] this thread writes (the
-    // descriptor fetch is off the tail of the block)
-    constexpr int kItems = (kSpCh * (NC + 1) + 255) / 256;
+    // for the combine step at the end: which partial[q + 1] this thread writes; its channel's
+    // descriptor is fetched now, so that no memory round trip is left on the tail of the block
+    constexpr int kItems = kWholeBlock ? (kSpCh * (NC + 1) + 64 * WAVES - 1) / (64 * WAVES) : 1;
     bool on[kItems];
     float om_item[kItems];
+    if (kWholeBlock) {
 #pragma unroll
-    for (int e = 0; e < kItems; ++e) {
-        const int item = t + 256 * e;
-        const int ci = g * kSpCh + item / (NC + 1);
-        on[e] = item < kSpCh * (NC + 1) && ci < P.nch;
-        const JobMid m2 = mid[b * P.nch + (on[e] ? ci : 0)];
-        on[e] = on[e] && m2.active;
-        om_item[e] = m2.om;
+        for (int e = 0; e < kItems; ++e) {
+            const int item = (int)threadIdx.x + 64 * WAVES * e;
+            const int ci = g * kSpCh + item / (NC + 1);
+            on[e] = item < kSpCh * (NC + 1) && ci < P.nch;
+            const JobMid m2 = mid[b * P.nch + (on[e] ? ci : 0)];
+            on[e] = on[e] && m2.active;
+            om_item[e] = m2.om;
+        }
     }
+    const float2* blk = iq + (size_t)b * ((size_t)CS * NC);
+    float* tl = &lds[wave][0];
     sp4 tot[2][2], lo_fin[2][2];
     bool all_lo[2];
-    span_wave<kSpQuarter / kSpTile, DIAG>(blk, tl, cd, mid + (size_t)b * P.nch + g * kSpCh, nch_g, code_eo,
-                                          wave * kSpQuarter, lane, tot, lo_fin, all_lo);
+    int pb[2];
+    span_wave<NSPANS, DIAG>(blk, tl, tl + kSpTileFloats, mid + (size_t)b * P.nch + g * kSpCh,
+                            P.nch - g * kSpCh, code_eo, range * NSPANS * kSpTile, lane, tot, lo_fin, all_lo, pb);
     if (DIAG & 4) {
-        if (tot[0][0][0] + tot[1][1][1] + lo_fin[0][1][2] + lo_fin[1][0][3] == 123.456f)
-            partial[(size_t)b * P.nch * (NC + 1) + t] = make_float2(tot[0][0][0], tot[1][0][0]);
+        if (tot[0][0][0] + tot[1][1][1] + lo_fin[0][1][2] + lo_fin[1][0][3] != 123.456f) return;
+    }
+    if (!kWholeBlock) {
+        float* o = rec + ((size_t)unit * kRanges + range) * kSpRecFloats + lane;
+        const int rel0 = (range * NSPANS * kSpTile) & (kSpQuarter - 1);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const bool closed = pb[n] > rel0 && pb[n] < rel0 + NSPANS * kSpTile;   // lo was closed in this range
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    o[((mt * 2 + n) * 4 + v) * 64] = tot[mt][n][v];
+                    if (closed) o[kSpLoOfs + ((mt * 2 + n) * 4 + v) * 64] = lo_fin[mt][n][v];
+                }
+        }
         return;
     }
-    [[maybe_unused]] const unsigned long long ts1 = SP_STAMP();
-
-    // ---- per wave: hi / lo sums of every row into LDS.  D[i = 4 (lane / 16) + v][j = lane % 16]
+    // ---- whole block in the workgroup: hi / lo sums of every row of the quarter into LDS
+    // (the wave's own tile area), D[i = 4 (lane / 16) + v][j = lane % 16]; behind one barrier
+    // all threads add the quarters in their fixed order, apply U and write partial[q + 1],
+    // q = -1 .. 31
+    constexpr int kSumFloats = kSpCh * NC * 2;          // [channel][row][re, im]
+    static_assert(2 * kSumFloats <= kSpTileFloats, "row sums must fit the tile area");
     {
         float* hi = tl;
         float* lo = tl + kSumFloats;
@@ -494,10 +490,11 @@ __global__ __launch_bounds__(256, 2) void trk_span_kernel(
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             const int c = 8 * n + (j >> 1);
+            const sp4 z = sp4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
-                sp4 w_hi, w_lo;
-                span_sides(tot[mt][n], lo_fin[mt][n], all_lo[n], w_hi, w_lo);
+                const sp4 w_hi = all_lo[n] ? z : tot[mt][n];
+                const sp4 w_lo = all_lo[n] ? tot[mt][n] : lo_fin[mt][n];
                 if (c < kSpCh) {
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
@@ -509,24 +506,23 @@ __global__ __launch_bounds__(256, 2) void trk_span_kernel(
             }
         }
     }
-    // ---- combine the quarters (fixed order), apply U, write partial[q + 1], q = -1 .. 31
+    // the row factors (double arithmetic) before the barrier, the sums behind it
     float2 u0[kItems], u1[kItems];
 #pragma unroll
     for (int e = 0; e < kItems; ++e) {
-        const int q = (t + 256 * e) % (NC + 1) - 1;
+        const int q = ((int)threadIdx.x + 64 * WAVES * e) % (NC + 1) - 1;
         u0[e] = sp_row_factor(om_item[e], q);
         u1[e] = sp_row_factor(om_item[e], q + 1);
     }
     __syncthreads();
-    [[maybe_unused]] const unsigned long long ts2 = SP_STAMP();
 #pragma unroll
     for (int e = 0; e < kItems; ++e) {
         if (!on[e]) continue;
-        const int item = t + 256 * e;
+        const int item = (int)threadIdx.x + 64 * WAVES * e;
         const int cc = item / (NC + 1), o = item % (NC + 1), q = o - 1;
         float hx = 0.f, hy = 0.f, lx = 0.f, ly = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < WAVES; ++w) {
             const float* hi = &lds[w][0];
             const float* lo = hi + kSumFloats;
             if (q >= 0) { hx += hi[(cc * NC + q) * 2]; hy += hi[(cc * NC + q) * 2 + 1]; }
@@ -534,79 +530,47 @@ __global__ __launch_bounds__(256, 2) void trk_span_kernel(
         }
         partial[((size_t)b * P.nch + g * kSpCh + cc) * (NC + 1) + o] = sp_window(hx, hy, lx, ly, u0[e], u1[e]);
     }
-#ifdef GPSMI_SP_PROF
-    if (lane == 0 && g_sp_prof) {
-        unsigned long long* o = g_sp_prof + ((size_t)wg * 4 + wave) * 4;
-        o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = clock64();
-    }
-#endif
 }
 
-// ---- single-block form: every span is a wave of its own (32 waves per block and channel
-// group on eight workgroups), for a launch too small to fill the CUs with whole blocks (the
-// closed loop).  A wave writes its raw sums; span_collect (called by the epilogue kernel)
-// adds them up in the order the batch form uses, so both forms give the same bits.
-//   spanout[unit = b * ngroups + g][span 0..31][tot | lo_fin][M tile][N tile][v][lane]
-constexpr int kSpSpanOutFloats = 2 * 16 * 64;          // one wave
-constexpr int kSpUnitOutFloats = 32 * kSpSpanOutFloats;   // one (block, channel group): 256 KiB
-
-__global__ __launch_bounds__(256, 2) void trk_span_single_kernel(
-    const float2* __restrict__ iq, const JobMid* __restrict__ mid,
-    const float* __restrict__ code_eo, TrkParams P, int ngroups, int nblocks,
-    float* __restrict__ spanout) {
-    constexpr int NC = 32, CS = kFftN;
-    __shared__ __attribute__((aligned(16))) float lds[4][kSpWaveFloats];
-    const int unit = blockIdx.x >> 3, sub = blockIdx.x & 7;
-    const int g = unit % ngroups, b = unit / ngroups;
-    if (b >= nblocks) return;
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int span = 4 * sub + wave;
-    const float2* blk = iq + (size_t)b * ((size_t)CS * NC);
-    float* tl = &lds[wave][0];
-    sp4 tot[2][2], lo_fin[2][2];
-    bool all_lo[2];
-    span_wave<1>(blk, tl, tl + kSpTileFloats, mid + (size_t)b * P.nch + g * kSpCh, P.nch - g * kSpCh, code_eo,
-                 span * kSpTile, lane, tot, lo_fin, all_lo);
-    float* o = spanout + (size_t)unit * kSpUnitOutFloats + (size_t)span * kSpSpanOutFloats + lane;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                o[(((0 * 2 + mt) * 2 + n) * 4 + v) * 64] = tot[mt][n][v];
-                o[(((1 * 2 + mt) * 2 + n) * 4 + v) * 64] = lo_fin[mt][n][v];
-            }
-}
-
-// One wave per job: the sums of the 32 spans of channel `cidx` of block `b` -> S[0 .. 32]
-// (= partial[job][.]) in LDS.  lane = (row, re/im).  hi / lo: 64 floats of LDS each.
-__device__ __forceinline__ void span_collect(const float* __restrict__ spanout, int ngroups, int b,
-                                             int cidx, int d, float om, int lane, float* hi, float* lo,
-                                             float2* S) {
+// One wave per job: the sums of the ranges of channel `cidx` of block `b` -> S[0 .. 32]
+// (= what the other correlators write to partial[job][.]) in LDS.  lane = (row, re/im);
+// hi / lo: 64 floats of LDS each.  NSPANS = spans per record, as the kernel that wrote them.
+template <int NSPANS>
+__device__ __forceinline__ void span_collect(const float* __restrict__ rec, int ngroups, int b, int cidx,
+                                             int d, float om, int lane, float* hi, float* lo, float2* S) {
     constexpr int NC = 32;
+    constexpr int kPerQ = kSpQuarter / (NSPANS * kSpTile);   // records per quarter: 1 or 8
+    constexpr int kLen = NSPANS * kSpTile;                   // positions per record
     const int g = cidx / kSpCh, cc = cidx % kSpCh;
     const int r = lane >> 1, part = lane & 1;
     const int n = cc >> 3, j = 2 * (cc & 7) + part, mt = r >> 4, rg = (r & 15) >> 2, v = r & 3;
-    const float* src = spanout + (size_t)(b * ngroups + g) * kSpUnitOutFloats
-                       + (((0 * 2 + mt) * 2 + n) * 4 + v) * 64 + 16 * rg + j;
-    constexpr int kLo = 16 * 64;                       // offset of lo_fin within a span's record
+    const float* src = rec + (size_t)(b * ngroups + g) * (4 * kPerQ) * kSpRecFloats
+                       + ((mt * 2 + n) * 4 + v) * 64 + 16 * rg + j;
     float h = 0.f, l = 0.f;
-#pragma unroll 1
+#pragma unroll
     for (int Q = 0; Q < 4; ++Q) {
         const int rel = d - Q * kSpQuarter;
         const bool all_lo = rel >= kSpQuarter;
         const int pb = (rel > 0 && rel < kSpQuarter) ? rel : kSpInf;
         float T = 0.f, L = 0.f;
 #pragma unroll
-        for (int s8 = 0; s8 < kSpQuarter / kSpTile; ++s8) {
-            const float* p = src + (size_t)(8 * Q + s8) * kSpSpanOutFloats;
-            if (pb >= s8 * kSpTile && pb < (s8 + 1) * kSpTile) {   // the boundary closes lo here
-                L = T + p[kLo];
-                T = 0.f;
+        for (int s = 0; s < kPerQ; ++s) {
+            const float* p = src + (size_t)(kPerQ * Q + s) * kSpRecFloats;
+            const float t = p[0];
+            if (kPerQ == 1) {
+                // the wave that summed the quarter closed lo itself where the boundary passed
+                T = t;
+                if (pb != kSpInf) L = p[kSpLoOfs];
+            } else {
+                if (pb > s * kLen && pb < (s + 1) * kLen) {        // closed inside this range
+                    L = T + p[kSpLoOfs];
+                    T = 0.f;
+                } else if (pb == s * kLen) {                       // ... exactly at its start
+                    L = T + 0.f;
+                    T = 0.f;
+                }
+                T = T + t;
             }
-            T = T + p[0];
         }
         h += all_lo ? 0.f : T;
         l += all_lo ? T : L;

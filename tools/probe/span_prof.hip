@@ -5,12 +5,12 @@
 //         tools/probe/span_prof.hip gps-sdr-receiver_amd/csrc/gpsmi_core.hip \
 //         gps-sdr-receiver_amd/csrc/gpsmi_acq.hip -o tools/probe/span_prof
 //   tools/probe/span_prof [blocks = 1024]
-// (-DGPSMI_SP_PROF: per-wave cycle stamps instead of the timing runs)
 #include "../../gps-sdr-receiver_amd/csrc/gpsmi_trk.hip"
 
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 
 using namespace gpsmi;
 
@@ -41,24 +41,40 @@ __global__ void ref_kernel(const float2* iq, const JobMid* mid, const float* cod
 }
 
 struct Bufs {
-    float2* iq; JobMid* mid; float* code2; float* code_eo; float2* partial; double* ref;
+    float2* iq; JobMid* mid; float* code2; float* code_eo; float2* partial; float* rec; double* ref;
 };
 
+// what the epilogue kernel does with the records: one wave per job -> partial[job][0 .. 32]
+template <int NSP>
+__global__ void collect_kernel(const float* rec, const JobMid* mid, int ngroups, int nch, int njobs,
+                               float2* partial) {
+    __shared__ float hi[4][64], lo[4][64];
+    __shared__ float2 S[4][GPSMI_MAX_DUMPS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, job = blockIdx.x * 4 + wave;
+    if (job >= njobs || !mid[job].active) return;
+    span_collect<NSP>(rec, ngroups, job / nch, job % nch, mid[job].delay_used, mid[job].om, lane, hi[wave],
+                      lo[wave], S[wave]);
+    if (lane <= 32) partial[(size_t)job * 33 + lane] = S[wave][lane];
+}
+
+template <int NSP, int WAVES, int DIAG>
+static void launch_span_t(const Bufs& B, int nblocks, int nch, bool collect) {
+    TrkParams P{};
+    P.cs = 2048; P.n_cyc = 32; P.nch = nch;
+    const int ng = (nch + kSpCh - 1) / kSpCh;
+    hipLaunchKernelGGL((trk_span_kernel<NSP, WAVES, DIAG>), dim3(nblocks * ng * (32 / NSP) / WAVES),
+                       dim3(64 * WAVES), 0, 0, B.iq, B.mid, B.code_eo, P, ng, nblocks, B.rec, B.partial);
+    if (collect && NSP * WAVES != 32)
+        hipLaunchKernelGGL(collect_kernel<NSP>, dim3((nblocks * nch + 3) / 4), dim3(256), 0, 0, B.rec, B.mid, ng,
+                           nch, nblocks * nch, B.partial);
+}
 template <int DIAG>
-static void launch_span_diag(const Bufs& B, int nblocks, int nch) {
-    TrkParams P{};
-    P.cs = 2048; P.n_cyc = 32; P.nch = nch;
-    const int ng = (nch + kSpCh - 1) / kSpCh;
-    hipLaunchKernelGGL(trk_span_kernel<DIAG>, dim3(((nblocks + 7) / 8) * 8 * ng), dim3(256), 0, 0, B.iq, B.mid,
-                       B.code_eo, P, ng, nblocks, B.partial);
-}
-static void launch_span(const Bufs& B, int nblocks, int nch) {
-    TrkParams P{};
-    P.cs = 2048; P.n_cyc = 32; P.nch = nch;
-    const int ng = (nch + kSpCh - 1) / kSpCh;
-    hipLaunchKernelGGL(trk_span_kernel<0>, dim3(((nblocks + 7) / 8) * 8 * ng), dim3(256), 0, 0, B.iq, B.mid,
-                       B.code_eo, P, ng, nblocks, B.partial);
-}
+static void launch_span_diag(const Bufs& B, int nblocks, int nch) { launch_span_t<8, 4, DIAG>(B, nblocks, nch, false); }
+static void launch_span(const Bufs& B, int nblocks, int nch) { launch_span_t<8, 4, 0>(B, nblocks, nch, false); }
+static void launch_span_c(const Bufs& B, int nblocks, int nch) { launch_span_t<8, 4, 0>(B, nblocks, nch, true); }
+static void launch_single_c(const Bufs& B, int nblocks, int nch) { launch_span_t<1, 1, 0>(B, nblocks, nch, true); }
+static void launch_single(const Bufs& B, int nblocks, int nch) { launch_span_t<1, 1, 0>(B, nblocks, nch, false); }
+static void launch_single4(const Bufs& B, int nblocks, int nch) { launch_span_t<1, 4, 0>(B, nblocks, nch, false); }
 static void launch_mfma(const Bufs& B, int nblocks, int nch) {
     TrkParams P{};
     P.cs = 2048; P.n_cyc = 32; P.nch = nch;
@@ -134,38 +150,6 @@ static void set_delays(Bufs& B, int nblocks, int nch, int mode) {
     hipMemcpy(B.mid, mid.data(), mid.size() * sizeof(JobMid), hipMemcpyHostToDevice);
 }
 
-#ifdef GPSMI_SP_PROF
-static void prof(const Bufs& B, int nblocks, int nch) {
-    const size_t nw = (size_t)((nblocks + 7) / 8) * 8 * 4;
-    unsigned long long* d; hipMalloc((void**)&d, nw * 32);
-    hipMemcpyToSymbol(HIP_SYMBOL(g_sp_prof), &d, sizeof(d));
-    unsigned long long z4[4] = {0, 0, 0, 0};
-    for (int it = 0; it < 3; ++it) {
-        hipMemset(d, 0, nw * 32);
-        hipMemcpyToSymbol(HIP_SYMBOL(g_sp_acc), z4, 32);
-        launch_span(B, nblocks, nch);
-        hipDeviceSynchronize();
-    }
-    std::vector<unsigned long long> r(nw * 4);
-    hipMemcpy(r.data(), d, nw * 32, hipMemcpyDeviceToHost);
-    double loop = 0, bar = 0, comb = 0; unsigned long long tmin = ~0ull, tmax = 0; size_t n = 0;
-    std::vector<unsigned long long> starts;
-    for (size_t w = 0; w < nw; ++w) {
-        const unsigned long long* o = &r[w * 4];
-        if (!o[3]) continue;
-        loop += o[1] - o[0]; bar += o[2] - o[1]; comb += o[3] - o[2]; ++n;
-        tmin = std::min(tmin, o[0]); tmax = std::max(tmax, o[3]);
-        starts.push_back(o[0]);
-    }
-    std::sort(starts.begin(), starts.end());
-    hipMemcpyFromSymbol(z4, HIP_SYMBOL(g_sp_acc), 32);
-    printf("prof: %zu waves; per wave: set-up + loop %.0f, to barrier %.0f, combine %.0f ticks\n", n, loop / n,
-           bar / n, comb / n);
-    printf("      of the first: set-up %.0f, wait for the first rows %.0f, the 8 tile tops (stores to LDS, "
-           "next loads) %.0f\n", (double)(z4[2] - z4[3]) / n, (double)z4[0] / n, (double)z4[1] / n);
-    hipFree(d);
-}
-#endif
 
 int main(int argc, char** argv) {
     const int nblocks = argc > 1 ? atoi(argv[1]) : 1024, nch = 12;
@@ -202,20 +186,25 @@ int main(int argc, char** argv) {
     hipMemcpy(B.code_eo, eo.data(), eo.size() * 4, hipMemcpyHostToDevice);
     hipMalloc((void**)&B.partial, (size_t)nblocks * nch * 33 * sizeof(float2));
     hipMalloc((void**)&B.ref, (size_t)64 * nch * 33 * 16);
+    hipMalloc((void**)&B.rec, (size_t)std::max(nblocks * 4, 32 * 32) * kSpRecFloats * sizeof(float));
 
-    const int ncheck = std::min(nblocks, 24);
+    const int ncheck = std::min(nblocks, 24);   // (<= 32: the record buffer holds 32 x 32 records)
     for (int mode = 0; mode < 4; ++mode) {
         set_delays(B, nblocks, nch, mode);
         printf("-- delays: %s\n", mode == 0 ? "spread" : mode == 1 ? "edges" : mode == 2 ? "one quarter" : "random, some closed");
         check("mfma<4>", launch_mfma, B, ncheck, nch);
-        check("span", launch_span, B, ncheck, nch);
-        if (mode == 3) check("span 5ch", launch_span, B, ncheck, 5);
+        check("span", launch_span_c, B, ncheck, nch);
+        check("span single", launch_single_c, B, ncheck, nch);
+        if (mode == 3) check("span 5ch", launch_span_c, B, ncheck, 5);
+        {   // the two forms must agree bit for bit
+            std::vector<float2> a((size_t)ncheck * nch * 33), c(a.size());
+            launch_span_c(B, ncheck, nch); hipDeviceSynchronize();
+            hipMemcpy(a.data(), B.partial, a.size() * 8, hipMemcpyDeviceToHost);
+            launch_single_c(B, ncheck, nch); hipDeviceSynchronize();
+            hipMemcpy(c.data(), B.partial, c.size() * 8, hipMemcpyDeviceToHost);
+            printf("batch form == single-block form: %s\n", memcmp(a.data(), c.data(), a.size() * 8) ? "NO" : "yes");
+        }
     }
-#ifdef GPSMI_SP_PROF
-    set_delays(B, nblocks, nch, 0);
-    prof(B, nblocks, nch);
-    return 0;
-#endif
     for (int mode : {0, 2}) {
         set_delays(B, nblocks, nch, mode);
         printf("-- delays: %s\n", mode == 0 ? "spread" : "one quarter");
@@ -232,6 +221,12 @@ int main(int argc, char** argv) {
     timeit("span diag 5", launch_span_diag<5>, B, nblocks, nch);
     timeit("span diag 6", launch_span_diag<6>, B, nblocks, nch);
     timeit("span diag 7", launch_span_diag<7>, B, nblocks, nch);
+    printf("-- single-block form, few blocks (latency)\n");
+    timeit("single", launch_single, B, 1, nch);
+    timeit("span", launch_span, B, 1, nch);
+    timeit("single", launch_single, B, 8, nch);
+    timeit("single 4w", launch_single4, B, 1, nch);
+    timeit("single 4w", launch_single4, B, 8, nch);
     {   // no boundary anywhere: every delay 0
         std::vector<JobMid> mid((size_t)nblocks * nch);
         hipMemcpy(mid.data(), B.mid, mid.size() * sizeof(JobMid), hipMemcpyDeviceToHost);
