@@ -204,8 +204,11 @@ static int acq_reserve(gpsmi_acq* h, int nbins, int nsv) {
 
 extern "C" {
 
+static int acq_build(const gpsmi_cfg* cfg, gpsmi_acq* h);
+
 int gpsmi_acq_create(const gpsmi_cfg* cfg, gpsmi_acq** out) {
     GPSMI_REQUIRE(cfg && out, "null argument");
+    *out = nullptr;
     GPSMI_REQUIRE(cfg->code_samples >= 1024 && cfg->code_samples <= 65536 &&
                       cfg->code_samples % 16 == 0,
                   "code_samples must be a multiple of 16 in 1024..65536");
@@ -214,7 +217,18 @@ int gpsmi_acq_create(const gpsmi_cfg* cfg, gpsmi_acq** out) {
     gpsmi_acq* h = new (std::nothrow) gpsmi_acq();
     if (!h) return fail(GPSMI_E_NOMEM, "out of host memory");
     h->cfg = *cfg;
+    const int rc = acq_build(cfg, h);
+    if (rc) {                       // nothing half-built leaves this function
+        (void)gpsmi_acq_destroy(h);
+        return rc;
+    }
     *out = h;
+    return GPSMI_OK;
+}
+
+}  // extern "C"
+
+static int acq_build(const gpsmi_cfg* cfg, gpsmi_acq* h) {
     h->direct = cfg->code_samples != kFftN;
     GPSMI_HIP(hipStreamCreate(&h->stream));
     GPSMI_HIP(hipEventCreateWithFlags(&h->order, hipEventDisableTiming));
@@ -258,6 +272,8 @@ int gpsmi_acq_create(const gpsmi_cfg* cfg, gpsmi_acq** out) {
     }
     return GPSMI_OK;
 }
+
+extern "C" {
 
 int gpsmi_acq_destroy(gpsmi_acq* h) {
     if (!h) return GPSMI_OK;

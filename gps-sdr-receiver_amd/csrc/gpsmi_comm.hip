@@ -44,11 +44,21 @@ int gpsmi_comm_create(const void* id_bytes, int nranks, int rank, int device, gp
     gpsmi_comm* c = new (std::nothrow) gpsmi_comm();
     if (!c) return fail(GPSMI_E_NOMEM, "out of host memory");
     c->nranks = nranks; c->rank = rank; c->device = device;
-    *out = c;
+    *out = nullptr;
     ncclUniqueId id;
     memcpy(&id, id_bytes, sizeof(id));
-    GPSMI_HIP(hipStreamCreate(&c->stream));
-    GPSMI_NCCL(ncclCommInitRank(&c->comm, nranks, id, rank));
+    hipError_t he = hipStreamCreate(&c->stream);
+    if (he != hipSuccess) {         // nothing half-built leaves this function
+        (void)gpsmi_comm_destroy(c);
+        return fail(GPSMI_E_HIP, "hipStreamCreate: %s", hipGetErrorString(he));
+    }
+    ncclResult_t nr = ncclCommInitRank(&c->comm, nranks, id, rank);
+    if (nr != ncclSuccess) {
+        c->comm = nullptr;
+        (void)gpsmi_comm_destroy(c);
+        return fail(GPSMI_E_COMM, "ncclCommInitRank: %s", ncclGetErrorString(nr));
+    }
+    *out = c;
     return GPSMI_OK;
 }
 

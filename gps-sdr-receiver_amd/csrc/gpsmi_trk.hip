@@ -565,8 +565,11 @@ static int trk_pull_state(gpsmi_trk* h) {
 
 extern "C" {
 
+static int trk_build(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk* h);
+
 int gpsmi_trk_create(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk** out) {
     GPSMI_REQUIRE(cfg && out, "null argument");
+    *out = nullptr;
     GPSMI_REQUIRE(max_ch >= 1 && max_ch <= 4096, "max_ch out of range");
     GPSMI_REQUIRE(cfg->code_samples >= 1024 && cfg->code_samples <= 65536 &&
                       cfg->code_samples % 16 == 0,
@@ -586,7 +589,18 @@ int gpsmi_trk_create(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk** out) {
         if (js && (atoi(js) == 4 || atoi(js) == 8)) h->stream_j = atoi(js);
     }
     h->nchunks = (cfg->code_samples + 256 * h->stream_j - 1) / (256 * h->stream_j);
+    const int rc = trk_build(cfg, max_ch, h);
+    if (rc) {                       // nothing half-built leaves this function
+        (void)gpsmi_trk_destroy(h);
+        return rc;
+    }
     *out = h;
+    return GPSMI_OK;
+}
+
+}  // extern "C"
+
+static int trk_build(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk* h) {
     GPSMI_HIP(hipStreamCreate(&h->stream));
     GPSMI_HIP(hipStreamCreate(&h->copy_stream));
     GPSMI_HIP(hipEventCreateWithFlags(&h->order, hipEventDisableTiming));
@@ -659,6 +673,8 @@ int gpsmi_trk_create(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk** out) {
     if (cgs && (atoi(cgs) == 2 || atoi(cgs) == 4 || atoi(cgs) == 6)) h->corr_cg = atoi(cgs);
     return trk_reserve(h, max_ch);
 }
+
+extern "C" {
 
 int gpsmi_trk_destroy(gpsmi_trk* h) {
     if (!h) return GPSMI_OK;

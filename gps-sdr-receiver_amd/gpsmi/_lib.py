@@ -14,7 +14,8 @@ MAX_DF = 128
 COMM_ID_BYTES = 128
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libgpsmi.so')
+# (GPSMI_LIB_PATH: another build of the same library, e.g. `make asan`'s host-sanitizer build)
+LIB_PATH = os.environ.get('GPSMI_LIB_PATH') or os.path.join(os.path.dirname(_HERE), 'lib', 'libgpsmi.so')
 
 
 class EngineError(RuntimeError):

@@ -299,6 +299,8 @@ class TrkEngine:
             raise ValueError('table must be [nb, max_ch]')
         if delay_used is not None:
             delay_used = np.ascontiguousarray(delay_used, dtype=np.int32)
+            if delay_used.shape != (nb, self.max_ch):
+                raise ValueError('delay_used must be [nb, max_ch]')
         check(self.lib.gpsmi_trk_replay_load(self.h, nb, ptr(table),
                                              ptr(delay_used)),
               'gpsmi_trk_replay_load')

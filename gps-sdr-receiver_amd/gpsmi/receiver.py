@@ -262,9 +262,27 @@ def _sweep_frequency(pool, hc, data):
     return sweeping, freq, nmc, delay, co_ph
 
 
-def satCalc(actSatSet, pool, poolWorker, data, smpTime):
+def initSweep(pool, wno, st=None):
+    """SatStream.initSweep (gpslib.py:1110-1116) for the channel in worker slot wno:
+    remember FREQ and DF (st: the engine state to fall back to, default the current
+    one), unlock, restart at MIN_FREQ; the engine channel is closed until the sweep ends."""
+    hc = pool.chan[wno]
+    if st is None:
+        st = pool.trk.get_state(wno)
+    hc.setPhaseUnlocked()
+    # FREQ is float32 once the PLL has run, a Python float right after initInst or a clamp
+    hc.FREQ_SAVE = st['freq'] if st['omega0'] == 0 else float(st['freq'])
+    hc.DF_SAVE = list(st['df'][:int(st['df_len'])])
+    hc.FREQ = pool.cfg.min_freq
+    hc.SWEEP = True
+    pool.trk.close_channel(wno)
+
+
+def satCalc(actSatSet, pool, poolWorker, data, smpTime, sweep=()):
     """gpsrecv.py:404-417 -> [(swFq, satNo, frameData, coPh, cpQ), ...] in the
-    iteration order of actSatSet, one engine call for all tracking channels."""
+    iteration order of actSatSet, one engine call for all tracking channels.
+    sweep: satellites whose channel is to start a sweep with this block, the
+    ``sweep=True`` argument of SatStream.process (gpslib.py:1141, :1147-1151)."""
     cfg = pool.cfg
     stream_no = smpTime // cfg.ngps
     order = [(sno, poolWorker.index(sno)) for sno in actSatSet]
@@ -276,6 +294,8 @@ def satCalc(actSatSet, pool, poolWorker, data, smpTime):
             if not hc.SWEEP:
                 pool.trk.erase_prev(wno)
         hc.PREV_STREAM_NO = stream_no
+        if sno in sweep and not hc.SWEEP:               # ignore the trigger if one is running
+            initSweep(pool, wno)
         # the state a sweep trigger must fall back to (gpslib.py:1110-1116)
         if (not hc.SWEEP and stream_no % hc.NO_SEC == 0
                 and len(hc.CORRLST) + 1 >= hc.CORRLST_NO):
@@ -297,25 +317,23 @@ def satCalc(actSatSet, pool, poolWorker, data, smpTime):
                 hc.FREQ = hc.FREQ_SAVE                  # restoreFreq
             if not hc.SWEEP:                            # back to tracking next block
                 pool.trk.open(wno, sno, hc.FREQ, hc.DELAY)
-                if delay < 0:
+                if delay < 0:                           # restoreFreq: FREQ_SAVE and DF_SAVE
                     st = pool.trk.get_state(wno)
                     n = len(hc.DF_SAVE)
                     st['df_len'] = n
                     st['df'][:n] = hc.DF_SAVE
+                    if isinstance(hc.FREQ_SAVE, np.float32):
+                        # FREQ is float32 again: the reference's next demodDoppler forms
+                        # float32(2 pi) * FREQ in float32, which the kernel does for omega0 == 0
+                        st['omega0'] = 0.0
                     pool.trk.set_state(wno, st)
             frames = []
             if stream_no % hc.NO_SEC == 0:
                 frames = [{}]
                 hc.reportValues(frames)
         else:
-            sweep, frames, code_phase = hc.absorb(out[wno], smpTime)
-            if sweep:                                   # initSweep (gpslib.py:1110-1116)
-                st = saved[wno]
-                hc.setPhaseUnlocked()
-                hc.FREQ_SAVE = st['freq']
-                hc.DF_SAVE = list(st['df'][:int(st['df_len'])])
-                hc.FREQ = cfg.min_freq
-                hc.SWEEP = True
-                pool.trk.close_channel(wno)             # re-opened when the sweep ends
+            trig, frames, code_phase = hc.absorb(out[wno], smpTime)
+            if trig:                                    # initSweep (gpslib.py:1110-1116) with the
+                initSweep(pool, wno, saved[wno])        # state before this block's PLL update
         res.append((hc.SWEEP, sno, frames, code_phase, (hc.CORR_Q, hc.CORR_L)))
     return res

@@ -1,7 +1,23 @@
-"""How the path shards over the GPUs of one node: satellites for
-acquisition, stream segments for tracking.  Pure host logic, shared by
-bench.py and the multi-process tests; the exchange itself is one all-gather of
-peak records (RCCL on the GPU, gpsmi_comm_allgather_peaks)."""
+"""How the path shards over the GPUs of one node.  Pure host
+logic, shared by bench.py and the multi-process tests.
+
+Acquisition: the SV list is split contiguously (32 SVs on 8 GPUs = 4 each,
+BASELINE configs[3]); every rank searches its shard on the same IQ and the
+one exchange of the path is an all-gather of the 16-byte peak records (RCCL on
+the GPU, gpsmi_comm_allgather_peaks).  A collective needs equal counts on every
+rank, so a shard is padded to ceil(nsv / world) columns by searching its last SV
+again (padded_shard); merge_peak_tables drops the pad columns.
+
+Tracking, two splits:
+ * by CHANNEL (the reference's own layout, one worker per SV, gpsrecv.py:340-360,
+   :404-417, and north_star's "SV channels shard"): channels round-robin over the
+   ranks (12 on 8 GPUs = 2,2,2,2,1,1,1,1), every rank reads the same IQ, the
+   per-channel outputs return through each rank's host and are merged in channel
+   order (shard_channels / merge_channel_outputs): no collective.  A fixed job is
+   cut up: strong scaling.
+ * in TIME (shard_blocks): rank r tracks its own segment of the stream from a
+   known trajectory (replay).  Per-rank work is fixed: weak scaling; this is what
+   bench.py --gpus N times by default, the other with --shard channels."""
 import numpy as np
 
 
@@ -15,6 +31,33 @@ def shard_blocks(first_block, blocks_per_rank, rank):
     """Time sharding of the stream: rank r owns blocks_per_rank consecutive blocks."""
     lo = first_block + rank * blocks_per_rank
     return lo, lo + blocks_per_rank
+
+
+def padded_shard(prns, rank, world):
+    """(SV list of this rank padded to the common width by repeating its last SV,
+    number of real SVs, width).  An empty shard (more ranks than SVs) searches
+    prns[0] `width` times and contributes no column."""
+    mine = shard_svs(prns, rank, world)
+    width = -(-len(prns) // world)
+    fill = mine[-1] if mine else prns[0]
+    return mine + [fill] * (width - len(mine)), len(mine), width
+
+
+def shard_channels(nch, rank, world):
+    """Round-robin split of the tracking channels: rank r owns r, r + world, ..."""
+    return list(range(rank, nch, world))
+
+
+def merge_channel_outputs(parts, nch, world):
+    """parts[r]: array [nb, len(shard_channels(nch, r, world))] of per-block records of
+    rank r's channels -> [nb, nch] in channel order."""
+    first = next(p for p in parts if p.shape[1] > 0)
+    out = np.zeros((first.shape[0], nch), dtype=first.dtype)
+    for r in range(world):
+        idx = shard_channels(nch, r, world)
+        if idx:
+            out[:, idx] = parts[r]
+    return out
 
 
 def pad_table(table, width):

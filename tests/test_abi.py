@@ -66,6 +66,42 @@ def test_no_cpu_fallback():
         engine.TrkEngine()
 
 
+def test_failed_create_leaves_no_handle():
+    """Free-on-failure: a create call that fails (bad configuration, or no usable GPU)
+    destroys whatever it had built and hands back NULL, never a half-built handle."""
+    from gpsmi import _lib
+    lib = _lib.load()
+    bad = _lib.Cfg(1000, 32, 8, 4, 8.0, -5000.0, 5000.0, 0)          # code_samples not a multiple of 16
+    h = C.c_void_p(0xDEAD)
+    assert lib.gpsmi_trk_create(C.byref(bad), 12, C.byref(h)) == -1 and h.value is None
+    h = C.c_void_p(0xDEAD)
+    assert lib.gpsmi_acq_create(C.byref(bad), C.byref(h)) == -1 and h.value is None
+    no_dev = _lib.Cfg(2048, 32, 8, 4, 8.0, -5000.0, 5000.0, 4096)    # no such device anywhere
+    for create in (lambda p: lib.gpsmi_trk_create(C.byref(no_dev), 12, p),
+                   lambda p: lib.gpsmi_acq_create(C.byref(no_dev), p)):
+        h = C.c_void_p(0xDEAD)
+        assert create(C.byref(h)) == -2 and h.value is None              # GPSMI_E_HIP
+        assert len(lib.gpsmi_last_error()) > 0
+    idb = (C.c_ubyte * _lib.COMM_ID_BYTES)()
+    h = C.c_void_p(0xDEAD)
+    assert lib.gpsmi_comm_create(idb, 0, 0, 0, C.byref(h)) == -1         # bad nranks
+
+
+def test_abi_under_host_sanitizers():
+    """the host shim under ASan + UBSan (`make asan-test`: this file's
+    other tests against lib/libgpsmi_asan.so with the sanitizer runtime preloaded)."""
+    import shutil
+    import subprocess
+    if os.environ.get('GPSMI_LIB_PATH'):
+        pytest.skip('already running against an alternative build')
+    if not (shutil.which('hipcc') or os.path.exists('/opt/rocm/bin/hipcc')):
+        pytest.skip('no hipcc to build the sanitizer variant')
+    r = subprocess.run(['make', '-C', os.path.join(ROOT, 'gps-sdr-receiver_amd'), 'asan-test'],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert 'passed' in r.stdout and 'ERROR: AddressSanitizer' not in r.stdout + r.stderr
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, 'gps-sdr-receiver_amd')
     for dirpath, _, files in os.walk(pkg):

@@ -76,6 +76,53 @@ def test_stream_gap_resets_carry(golden_default):
     R.closeMultiProcPool(pool)
 
 
+@pytest.mark.parametrize('case', ['two_calls', 'one_call', 'no_signal'])
+def test_resweep_matches_reference(case):
+    """Per-channel re-acquisition against the real SatStream (tests/golden/ref_resweep.npz,
+    gpslib.py:1110-1120, :1153-1173, :1350-1380): tracking, a sweep triggered the way
+    process(..., sweep=True) does, the sweep blocks through the acquisition engine, tracking
+    again.  SWEEP flag, FREQ of the sweep blocks and DELAY bit-exact; codePhase atol 2e-3,
+    MAX_CORR rtol 1e-3, FREQ of the tracking blocks atol 0.05 Hz."""
+    from conftest import load_golden
+    from gpsmi import receiver as R
+    g = load_golden('ref_resweep.npz')
+    sv, f0, d0, n_before, n_after = g[case + '_init']
+    sv, d0, n_before, nb = int(sv), int(d0), int(n_before), int(n_before + n_after)
+    first = int(g['first_block'])
+    found = [(20.0, sv, float(f0), d0)]
+    pool, n, worker = R.initMultiProcPool(1)
+    worker, act = R.initPoolStreams(pool, n, worker, set(), {sv}, found)
+    blocks = scene_blocks('default', first, nb)
+    hc = pool.chan[0]
+    for i in range(nb):
+        smp = np.int64((first + i + 1) * 65536)
+        res = R.satCalc(act, pool, worker, blocks[i], smp, sweep=({sv} if i == n_before else ()))
+        sw, sno, frames, co_ph, (cq, cl) = res[0]
+        where = f'{case} block {i}'
+        assert bool(sw) == bool(g[case + '_sweep'][i]), where
+        assert sno == sv
+        assert int(hc.DELAY) == int(g[case + '_delay'][i]), where
+        assert cq == g[case + '_corr_q'][i] and cl == g[case + '_corr_l'][i], where
+        assert len(frames) == int(g[case + '_n_frames'][i]), where
+        if frames:
+            assert float(frames[0]['SWP']) == g[case + '_swp_reported'][i], where
+        ref_cp = g[case + '_code_phase'][i]
+        if ref_cp < 0:
+            assert co_ph == -1, where
+        else:
+            assert abs(co_ph - ref_cp) < 2e-3, where
+        # FREQ: a Python float while it is a bin frequency of the sweep (exact), float32 once
+        # the PLL has run or restoreFreq has put FREQ_SAVE back (tracking tolerance)
+        assert isinstance(hc.FREQ, np.float32) == bool(g[case + '_freq_is_f32'][i]), where
+        if not g[case + '_freq_is_f32'][i]:
+            assert float(hc.FREQ) == g[case + '_freq'][i], where
+        else:
+            assert abs(float(hc.FREQ) - g[case + '_freq'][i]) < 0.05, where
+        np.testing.assert_allclose(hc.MAX_CORR, g[case + '_max_corr'][i], rtol=1e-3, err_msg=where)
+        assert bool(hc.PHASE_LOCKED) == bool(g[case + '_locked'][i]), where
+    R.closeMultiProcPool(pool)
+
+
 def test_resweep_reacquires_a_lost_channel(golden_default):
     """gpslib.py:1153-1173 + :1350-1380: a channel put into SWEEP finds its
     satellite again through the acquisition engine and returns to tracking."""

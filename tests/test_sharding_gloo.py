@@ -33,13 +33,12 @@ def _worker(rank, world, port, q):
     prns = list(range(1, 12))                       # 11 SVs: uneven split
     freqs = [-500.0, 0.0, 500.0]
     data = synth.default_scene(3, seed=5, prns=[2, 7, 11]).block(0, n=4096)
-    mine = sharding.shard_svs(prns, rank, world)
+    mine, n_real, width = sharding.padded_shard(prns, rank, world)   # as bench.py does
     t = orc.acq_table(data, freqs, mine, 2, orc.Params())
-    tab = np.zeros((len(freqs), len(mine)), dtype=PEAK_DTYPE)
+    tab = np.zeros((len(freqs), width), dtype=PEAK_DTYPE)
     for k in ('argmax', 'peak', 'mean', 'std'):
         tab[k] = t[k]
-    width = -(-len(prns) // world)
-    send = torch.from_numpy(sharding.pad_table(tab, width).view(np.uint8).copy())
+    send = torch.from_numpy(tab.view(np.uint8).copy())
     recv = [torch.empty_like(send) for _ in range(world)]
     dist.all_gather(recv, send)
     gathered = [r.numpy().view(PEAK_DTYPE).reshape(len(freqs), width) for r in recv]
@@ -55,19 +54,82 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_sv_sharding_and_gather_world2():
+def _run_world(target, world):
     import multiprocessing as mp
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=target, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    ok, tmax, shape = q.get(timeout=240)
+    res = q.get(timeout=300)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    return res
+
+
+def test_sv_sharding_and_gather_world2():
+    ok, tmax, shape = _run_world(_worker, 2)
     assert ok and tmax == 2.0 and shape == (3, 11)
+
+
+def test_sv_sharding_and_gather_world3_uneven():
+    """11 SVs on 3 ranks (4, 3, 4): the shards are padded to equal counts for the gather."""
+    ok, tmax, shape = _run_world(_worker, 3)
+    assert ok and tmax == 3.0 and shape == (3, 11)
+
+
+def _track_worker(rank, world, port, q):
+    """Channel-sharded tracking (the reference's one-worker-per-SV layout): every rank
+    runs ITS channels on the same blocks, the records are gathered and merged in channel
+    order; must equal the unsharded run.  Stand-in compute: the oracle's SatStream."""
+    sys.path[:0] = [os.path.join(ROOT, 'gps-sdr-receiver_amd'), os.path.join(ROOT, 'oracle')]
+    import torch
+    import torch.distributed as dist
+    import gps_oracle as orc
+    from gpsmi import sharding, synth
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    p = orc.Params()
+    chans = [(21, 3200.0, 1458), (4, -2000.0, 143), (6, 1200.0, 1023)]     # of the fixture scene
+    nb = 3
+    sc = synth.default_scene(12, seed=7)
+    blocks = [sc.block(5 + i) for i in range(nb)]
+    rec_dt = np.dtype([('delay', 'i4'), ('freq', 'f4'), ('phase', 'f4'), ('code_phase', 'f8')])
+
+    def run(idx):
+        out = np.zeros((nb, len(idx)), dtype=rec_dt)
+        for k, c in enumerate(idx):
+            sv, f0, d0 = chans[c]
+            ss = orc.SatStream(sv, f0, p, delay=d0)
+            for i in range(nb):
+                _, _, co_ph, _ = ss.process(blocks[i], np.int64((5 + i + 1) * p.ngps))
+                out[i, k] = (ss.delay, ss.freq, ss.phase, co_ph)
+        return out
+
+    mine = sharding.shard_channels(len(chans), rank, world)
+    width = -(-len(chans) // world)
+    loc = np.zeros((nb, width), dtype=rec_dt)
+    loc[:, :len(mine)] = run(mine)
+    send = torch.from_numpy(loc.view(np.uint8).copy())
+    recv = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(recv, send)           # (on the GPU path the records return through each host)
+    parts = []
+    for r in range(world):
+        n = len(sharding.shard_channels(len(chans), r, world))
+        parts.append(recv[r].numpy().view(rec_dt).reshape(nb, width)[:, :n])
+    merged = sharding.merge_channel_outputs(parts, len(chans), world)
+    dist.barrier()
+    if rank == 0:
+        full = run(list(range(len(chans))))
+        q.put((merged.tobytes() == full.tobytes(), merged.shape))
+    dist.destroy_process_group()
+
+
+def test_channel_sharded_tracking_merge_world2():
+    ok, shape = _run_world(_track_worker, 2)
+    assert ok and shape == (3, 3)
 
 
 def test_shards_tile_the_sv_list():
@@ -77,3 +139,10 @@ def test_shards_tile_the_sv_list():
         got = sum((sharding.shard_svs(prns, r, world) for r in range(world)), [])
         assert got == prns
     assert sharding.shard_blocks(5, 1024, 3) == (5 + 3072, 5 + 4096)
+    # tracking channels round-robin: 12 on 8 ranks = 2,2,2,2,1,1,1,1
+    assert [len(sharding.shard_channels(12, r, 8)) for r in range(8)] == [2, 2, 2, 2, 1, 1, 1, 1]
+    assert sorted(sum((sharding.shard_channels(12, r, 8) for r in range(8)), [])) == list(range(12))
+    for world in (2, 3, 5, 8):      # padded shards: equal counts, pad = a repeated SV
+        for r in range(world):
+            mine, n, width = sharding.padded_shard(prns, r, world)
+            assert len(mine) == width == -(-32 // world) and mine[:n] == sharding.shard_svs(prns, r, world)

@@ -132,6 +132,62 @@ static void timeit(const char* name, F launch, const Bufs& B, int nblocks, int n
            gb / (sum / reps) * 1e3, gb / (sum / reps) * 1e3 / 80.0);
 }
 
+// a VALU-bound kernel of ~150 us in front of every timed launch: what the code-phase
+// correlation is to the correlator in a replay step (clock / power state, cache contents)
+__global__ void heater_kernel(float* out, int n) {
+    float a = threadIdx.x * 1e-3f, b = 1.0001f, c = 0.5f, d = 0.25f;
+    for (int i = 0; i < n; ++i) {
+        a = fmaf(a, b, c); c = fmaf(c, b, d); d = fmaf(d, b, a); b = fmaf(b, 0.99999f, 1e-6f);
+    }
+    if (a + c + d == 123.f) out[0] = a;
+}
+// reads another 512 MiB (what lies in the 256 MiB Infinity Cache afterwards is not ours)
+__global__ void flush_kernel(const float4* src, size_t n, float* out) {
+    float a = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = src[i];
+        a += v.x + v.y + v.z + v.w;
+    }
+    if (a == 123.456f) out[0] = a;
+}
+static float4* g_flush = nullptr;
+template <class F>
+static void time_cold(const char* name, F launch, const Bufs& B, int nblocks, int nch) {
+    const size_t n = (size_t)512 << 20 >> 4;
+    if (!g_flush) { hipMalloc((void**)&g_flush, n * 16); hipMemset(g_flush, 0, n * 16); }
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float sum = 0; const int reps = 10;
+    for (int r = 0; r < reps + 2; ++r) {
+        hipLaunchKernelGGL(flush_kernel, dim3(4096), dim3(256), 0, 0, g_flush, n, (float*)B.ref);
+        hipEventRecord(e0, 0);
+        launch(B, nblocks, nch);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (r >= 2) sum += ms;
+    }
+    printf("cold  %-12s %4d blocks x %2d ch: %.4f ms (event pair around one launch) behind a read of another 512 MiB\n",
+           name, nblocks, nch, sum / reps);
+}
+template <class F>
+static void time_hot(const char* name, F launch, const Bufs& B, int nblocks, int nch, int heat) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float sum = 0; const int reps = 10;
+    for (int r = 0; r < reps + 2; ++r) {
+        hipLaunchKernelGGL(heater_kernel, dim3(2048), dim3(256), 0, 0, (float*)B.partial, heat);
+        hipEventRecord(e0, 0);
+        launch(B, nblocks, nch);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (r >= 2) sum += ms;
+    }
+    printf("hot   %-12s %4d blocks x %2d ch: %.4f ms (event pair around one launch) behind a VALU kernel of %d iterations\n",
+           name, nblocks, nch, sum / reps, heat);
+}
+
 static void set_delays(Bufs& B, int nblocks, int nch, int mode) {
     static const int edge[12] = {0, 1, 2, 127, 128, 129, 511, 512, 513, 1023, 2046, 2047};
     std::vector<JobMid> mid((size_t)nblocks * nch);
@@ -159,10 +215,14 @@ int main(int argc, char** argv) {
     {
         std::vector<float2> h(blk * 16);
         unsigned s = 12345;
-        for (auto& v : h) {
-            s = s * 1664525u + 1013904223u; v.x = ((int)(s >> 16) % 256 - 128) / 512.f;
-            s = s * 1664525u + 1013904223u; v.y = ((int)(s >> 16) % 256 - 128) / 512.f;
-        }
+        // full-mantissa values (sums of uniforms): the chip's clock under load depends on the
+        // operand bits, 8-bit values ran the kernels 10 % faster than real samples do
+        auto rnd = [&]() {
+            float a = 0;
+            for (int i = 0; i < 4; ++i) { s = s * 1664525u + 1013904223u; a += (float)(s >> 8) * (1.0f / 16777216.0f) - 0.5f; }
+            return a * 0.43f;
+        };
+        for (auto& v : h) { v.x = rnd(); v.y = rnd(); }
         for (int b = 0; b < nblocks; b += 16)
             hipMemcpy(B.iq + b * blk, h.data(), std::min(16, nblocks - b) * blk * sizeof(float2),
                       hipMemcpyHostToDevice);
@@ -173,7 +233,8 @@ int main(int argc, char** argv) {
     std::vector<float> code2((size_t)(GPSMI_MAX_PRN + 1) * 4096), eo(code2.size());
     for (int p = 0; p <= GPSMI_MAX_PRN; ++p)
         for (int i = 0; i < 2048; ++i) {
-            const float v = p == 0 ? 0.f : ((((unsigned)(p * 2048 + i) * 2654435761u) >> 13) & 1 ? 1.f : -0.75f);
+            const unsigned hsh = (unsigned)(p * 2048 + i) * 2654435761u;
+            const float v = p == 0 ? 0.f : ((hsh >> 13) & 1 ? 1.f : -1.f) * (((hsh >> 20) & 3) ? 1.f : 0.3f + (hsh >> 24) * 0.002f);
             code2[(size_t)p * 4096 + i] = code2[(size_t)p * 4096 + 2048 + i] = v;
         }
     for (int p = 0; p <= GPSMI_MAX_PRN; ++p)
@@ -215,6 +276,21 @@ int main(int argc, char** argv) {
     }
     set_delays(B, nblocks, nch, 0);
     printf("-- diagnostics (delays spread): 1 no MFMAs, 2 no row loads after the first tile, 4 no barrier / combine\n");
+    timeit("span", launch_span, B, nblocks, nch);
+    timeit("span no nt (8)", launch_span_diag<8>, B, nblocks, nch);
+    timeit("span", launch_span, B, nblocks, nch);
+    timeit("span no nt (8)", launch_span_diag<8>, B, nblocks, nch);
+    for (int heat : {0, 20000}) {
+        time_hot("span", launch_span, B, nblocks, nch, heat);
+        time_hot("mfma<4>", launch_mfma, B, nblocks, nch, heat);
+    }
+    time_cold("span", launch_span, B, nblocks, nch);
+    time_cold("mfma<4>", launch_mfma, B, nblocks, nch);
+    time_cold("span", launch_span, B, nblocks, nch);
+    time_cold("span no nt", launch_span_diag<8>, B, nblocks, nch);
+    time_cold("span diag 4", launch_span_diag<4>, B, nblocks, nch);
+    time_cold("span diag 5", launch_span_diag<5>, B, nblocks, nch);
+    time_cold("span diag 6", launch_span_diag<6>, B, nblocks, nch);
     timeit("span diag 4", launch_span_diag<4>, B, nblocks, nch);
     timeit("span diag 1", launch_span_diag<1>, B, nblocks, nch);
     timeit("span diag 2", launch_span_diag<2>, B, nblocks, nch);
