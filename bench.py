@@ -2,12 +2,16 @@
 """bench.py -- IQ Msamples/s ingested, 32-SV acquisition + 12-channel tracking.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--blocks NB]
+                    [--shard time|channels] [--no-cpu] [--no-extra]
 
-Workload (BASELINE.json configs[2] with configs[1] in front of it): a resident
-batch of NB 32-ms blocks of synthetic 2.048 Msps IQ (NB x 65536 complex64 in
-HBM, 512 MiB at the default NB = 1024), 12 tracking channels.  One step =
-  (a) one cold-acquisition search, 32 SV x 41 Doppler bins x 1 ms, on the first
-      millisecond of the batch (configs[1]), and
+Workload (BASELINE.json configs[2] with an acquisition search in front of it): a
+resident batch of NB 32-ms blocks of synthetic 2.048 Msps IQ (NB x 65536
+complex64 in HBM, 512 MiB at the default NB = 1024), 12 tracking channels.  One
+step =
+  (a) one cold-acquisition search on the first milliseconds of the batch:
+      N = 1: configs[1], 32 SV x 41 Doppler bins x 1 ms;
+      N > 1: configs[3], 32 SV x 201 bins x 10 ms with the SVs sharded over the
+             ranks (4 per GPU at N = 8) and one RCCL all-gather of the peak records;
   (b) 12-channel tracking of all NB blocks in replay mode: every block runs the
       complete SatStream.process arithmetic (carrier wipe-off, FFT code
       correlation + peak fit, prompt integrate-and-dump, amplitude statistics,
@@ -19,18 +23,25 @@ HBM, 512 MiB at the default NB = 1024), 12 tracking channels.  One step =
 value = NB * 65536 * n_gpus / step time.  The closed loop itself (state fed back
 block by block, launch-latency bound) is timed once and reported alongside.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the stream is
-sharded in time -- each rank tracks its own NB blocks -- and the acquisition
-search is sharded by SV with one RCCL all-gather of the peak records; no other
-data-path collective exists.  torch is used only for the rendezvous, the
-barrier and the max-over-ranks of the step time (gloo); it is not imported at
-N = 1.
+N > 1 (launched by torch.distributed.run, one rank per GPU).  Two splits of the
+tracking work (gpsmi/sharding.py):
+  --shard time      (default) every rank tracks its own NB blocks of the stream:
+                    per-rank work is fixed, "scaling": "weak";
+  --shard channels  north_star's split, one worker per SV as in the reference:
+                    the 12 channels round-robin over the ranks, every rank reads
+                    the same NB blocks: a fixed job is cut up, "scaling": "strong".
+No data-path collective exists besides the gather of peak records.  torch is used
+only for the rendezvous, the barrier and the max-over-ranks of the step time
+(gloo); it is not imported at N = 1.
 
 The printed JSON line carries `roofline` for the dominant kernel (the
-correlator, trk_stream_mfma_kernel: algorithmic bytes = NB*65536*8 per launch, time
-from HIP events on the engine's stream) and `cpu_baseline` (the numpy oracle
-fanned over host cores like the reference's one-process-per-SV pool, on a
-bounded sample of the same blocks; rank 0, N = 1 only).
+correlator, trk_span_kernel: algorithmic bytes = NB*65536*8 per launch, duration
+from the dispatch's own begin / end stamps -- hipExtLaunchKernel events on the
+engine's stream, what a kernel trace reports), `cpu_baseline` (the numpy oracle
+fanned over host cores like the reference's one-process-per-SV pool, on a bounded
+sample of the same blocks; rank 0, N = 1 only) and `configs`: BASELINE configs[3]
+(fine acquisition) and configs[4] (16.368 Msps tracking) timed on this GPU after
+the timed region.
 """
 import argparse
 import json
@@ -48,32 +59,35 @@ sys.path[:0] = [os.path.join(ROOT, 'gps-sdr-receiver_amd'),
 NGPS = 65536
 N_ACQ_BLOCKS = 5
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0          # same guide: measured float4 copy
 SEED = 7
 TIMED_EVERY = 4                # steps between two kernel-timed steps
 N_CH = 12
+PMC_FILE = os.path.join('profiles', 'round2', 'replay_pmc_counters.txt')
 
 
-def pmc_traffic():
-    """HBM bytes per correlator launch from the committed rocprofv3 --pmc run of
-    tools/kernel_bench.py (same kernel, same batch; separate counter passes):
-    FETCH_SIZE counts KiB and on gfx950 reports half of a wide coalesced read
-    stream (MI355X_MICROARCH.md, HBM), WRITE_SIZE is exact.  None if absent."""
-    path = os.path.join(ROOT, 'profiles', 'round1', 'replay_pmc_counters.txt')
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc pass of
+    tools/kernel_bench.py at this HEAD (same kernel, same batch; separate counter
+    passes): FETCH_SIZE counts KiB and on gfx950 reports half of a wide coalesced read
+    stream (MI355X_MICROARCH.md, HBM), WRITE_SIZE is exact.  (None, None) if absent:
+    this is NOT a measurement of the present run and is labelled as such."""
+    path = os.path.join(ROOT, PMC_FILE)
     try:
         fetch = write = None
         take = False
         for line in open(path):
             if not line.startswith(' '):
-                take = 'trk_stream_mfma_kernel' in line
+                take = kernel in line
             elif take and 'FETCH_SIZE' in line:
                 fetch = float(line.split()[1])
             elif take and 'WRITE_SIZE' in line:
                 write = float(line.split()[1])
         if fetch is None:
-            return None
-        return int(fetch * 1024 * 2 + (write or 0) * 1024)
+            return None, None
+        return int(fetch * 1024 * 2 + (write or 0) * 1024), PMC_FILE
     except OSError:
-        return None
+        return None, None
 
 
 # ---------------------------------------------------------------- input data
@@ -150,6 +164,64 @@ def cpu_baseline(raw, n_blocks, cores):
     }, found
 
 
+# ------------------------------------------------- the other BASELINE configs
+def measure_cfg4(E, acq, d_iq, reps=10):
+    """configs[3] on this GPU alone: 32 SV x 201 bins x 10 ms, device time per search."""
+    f201 = [-5000.0 + 50.0 * i for i in range(201)]
+    prns = list(range(1, 33))
+    ms = []
+    for i in range(reps + 2):
+        acq.engine.search((d_iq, 10 * 2048), prns, f201, 10)
+        if i >= 2:
+            ms.append(acq.engine.last_ms())
+    t = float(np.median(ms))
+    return {'config': 'BASELINE configs[3]: 32 SV x 201 Doppler bins x 10 ms coherent, one GPU '
+                      '(all 32 SVs)',
+            'us_per_search': round(t * 1e3, 1), 'searches_per_s': round(1e3 / t, 1),
+            'cells': 32 * 201, 'msamples_per_s': round(20480 / t / 1e3, 2),
+            'bound': 'LDS / VALU (FFT); algorithmic HBM bytes 0.75 MB per search'}
+
+
+def measure_cfg5(E, local, iters=8):
+    """configs[4]: 12-channel tracking at 16.368 Msps, N_CYC = 8 (block = 130944 samples),
+    512 blocks = 512 MiB resident, replay from a synthetic state table (random IQ: a
+    timing run; parity of this configuration is tests/test_gpu_trk.py on ref_hirate.npz)."""
+    cs, n_cyc, nb = 16368, 8, 512
+    ngps = cs * n_cyc
+    rng = np.random.default_rng(1)
+    trk = E.TrkEngine(E.Config(code_samples=cs, n_cyc=n_cyc, device=local), max_ch=N_CH)
+    buf = E.DeviceBuffer(nb * ngps * 8, local)
+    chunk = (rng.standard_normal((16, ngps, 2)) * 0.25).astype(np.float32)
+    for i in range(0, nb, 16):
+        buf.upload(chunk[:min(16, nb - i)], i * ngps * 8)
+    for c in range(N_CH):
+        trk.open(c, 2 + c, -4000.0 + 700.0 * c, (1137 * c + 11) % cs)
+    st = np.zeros((nb, N_CH), dtype=E.STATE_DTYPE)
+    for c in range(N_CH):
+        st[:, c] = trk.get_state(c)
+    st['phase'] = rng.uniform(0, 6.28, (nb, N_CH)).astype(np.float32)
+    dly = np.broadcast_to(st['delay'][0], (nb, N_CH)).copy()
+    trk.replay_load(nb, st, dly)
+    tot, cor = [], []
+    for i in range(iters + 2):
+        trk.replay_run(buf.ptr, nb)
+        if i >= 2:
+            t, c = trk.last_ms()
+            tot.append(t)
+            cor.append(c)
+    trk.close()
+    buf.free()
+    t, c = float(np.median(tot)), float(np.median(cor))
+    gb = nb * ngps * 8 / 1e9
+    return {'config': 'BASELINE configs[4]: 12-channel tracking @ 16.368 Msps, N_CYC = 8, '
+                      f'{nb} blocks x {ngps} complex64 = 512 MiB resident, replay',
+            'correlator_ms': round(c, 4), 'correlator_gbs': round(gb / c * 1e3, 1),
+            'correlator_frac_of_hbm_peak': round(gb / c * 1e3 / HBM_PEAK_GBS, 4),
+            'tracking_all_ms': round(t, 4),
+            'msamples_per_s': round(nb * ngps / t / 1e3, 1),
+            'x_realtime': round(nb * ngps / t / 1e3 / 16.368, 1)}
+
+
 # ---------------------------------------------------------------------- main
 def main():
     # stdout carries exactly one JSON line: whatever libraries print there while we run
@@ -163,6 +235,9 @@ def main():
     ap.add_argument('--blocks', type=int, default=1024)
     ap.add_argument('--cpu-blocks', type=int, default=192)
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='skip the configs[3] / configs[4] legs')
+    ap.add_argument('--shard', choices=('time', 'channels'), default='time',
+                    help='N > 1: how the tracking work is split over the ranks')
     ap.add_argument('--rehearse', action='store_true',
                     help='N > 1 on a box with fewer GPUs: ranks share devices, RCCL skipped')
     a = ap.parse_args()
@@ -175,20 +250,25 @@ def main():
             sys.exit('bench.py --gpus N > 1 must be launched with '
                      'python -m torch.distributed.run --nproc-per-node N')
         a.gpus = world
-    dist = None
+    dist = torch = None
     if world > 1:
-        import torch  # noqa: F401  (plumbing only; imported before libgpsmi)
+        # torch bundles its own libamdhip64 under the same SONAME: it is loaded first, and
+        # libgpsmi.so (not loaded yet: checked) then binds that one copy of the runtime
+        assert 'gpsmi._lib' not in sys.modules, 'torch must be imported before libgpsmi.so is loaded'
+        import torch
         import torch.distributed as dist
         dist.init_process_group('gloo')
 
     nb = a.blocks
     cores = os.cpu_count() or 1
     workers = max(1, min(16, cores // max(1, min(world, 8))))
+    by_channel = world > 1 and a.shard == 'channels'
 
     # ---- inputs (host, before HIP is initialised: fork pools)
-    first = rank * (nb + N_ACQ_BLOCKS)           # time-sharded stream
+    first = 0 if by_channel else rank * (nb + N_ACQ_BLOCKS)      # time-sharded stream
     t0 = time.perf_counter()
     raw = generate_raw(first, nb + N_ACQ_BLOCKS, workers)
+    raw0 = raw[0] if first == 0 else generate_raw(0, 1, 1)[0]    # the block every rank searches
     t_gen = time.perf_counter() - t0
 
     cpu = None
@@ -197,38 +277,50 @@ def main():
 
     # ---- GPU set-up
     from gpsmi import engine as E
+    from gpsmi import sharding
     from gpsmi.acquisition import Acquisition
     if a.rehearse:
         local = local % E.device_count()
     cfg = E.Config(device=local)
     dev_name = E.device_name(local)
     acq = Acquisition(cfg)
-    trk = E.TrkEngine(cfg, max_ch=N_CH)
     d_raw = E.DeviceBuffer(raw.nbytes, local)
     d_raw.upload(raw)
     d_iq = E.DeviceBuffer(raw.size * 8, local)
     E.unpack_u8iq(d_iq.ptr, d_raw.ptr, raw.size, local)   # streamData's decode
     d_raw.free()
     blk_bytes = NGPS * 8
+    d_iq0 = d_iq                                          # block 0 of the common stream
+    if first != 0:
+        d_raw0 = E.DeviceBuffer(raw0.nbytes, local)
+        d_raw0.upload(raw0)
+        d_iq0 = E.DeviceBuffer(raw0.size * 8, local)
+        E.unpack_u8iq(d_iq0.ptr, d_raw0.ptr, raw0.size, local)
+        d_raw0.free()
 
     # cold acquisition with the reference's own first-hit loop -> channels
     sat_lst, found, freq = list(range(2, 33)), [], cfg.min_freq
     for b in range(N_ACQ_BLOCKS):
         _, freq, found = acq.sweepAllSats((d_iq.at(b * blk_bytes), NGPS), freq,
                                           sat_lst, found, cfg.it_sweep_all)
-    chans = [(s, f, d) for _, s, f, d in found][:N_CH]
+    chans_all = [(s, f, d) for _, s, f, d in found][:N_CH]
+    my_ch = sharding.shard_channels(len(chans_all), rank, world) if by_channel \
+        else list(range(len(chans_all)))
+    chans = [chans_all[c] for c in my_ch]
+    nch = max(1, len(chans))
+    trk = E.TrkEngine(cfg, max_ch=nch)
     for c, (s, f, d) in enumerate(chans):
         trk.open(c, s, f, d)
 
     # closed loop over the batch: the trajectory (state at block start) + outputs
-    states = np.zeros((nb, N_CH), dtype=E.STATE_DTYPE)
-    cl_out = np.zeros((nb, N_CH), dtype=E.OUT_DTYPE)
+    states = np.zeros((nb, nch), dtype=E.STATE_DTYPE)
+    cl_out = np.zeros((nb, nch), dtype=E.OUT_DTYPE)
     trk_base = N_ACQ_BLOCKS * blk_bytes
     E.sync(local)
     t0 = time.perf_counter()
     cl_dev_ms = 0.0
     for i in range(nb):
-        for c in range(N_CH):
+        for c in range(nch):
             states[i, c] = trk.get_state(c)
         cl_out[i] = trk.process(d_iq.at(trk_base + i * blk_bytes))
         cl_dev_ms += trk.last_ms()[0]
@@ -245,12 +337,18 @@ def main():
     t_closed = time.perf_counter() - t0
     trk.set_timing(True)
 
-    # SV shard of the acquisition search + RCCL gather
+    # the acquisition leg of a step: configs[1] on one GPU, configs[3] sharded by SV on N
     prn_all = list(range(1, 33))
-    shard = prn_all[rank * 32 // world:(rank + 1) * 32 // world]
-    f41 = [-5000.0 + 250.0 * i for i in range(41)]
-    comm = d_send = d_recv = None
+    if world == 1:
+        acq_freqs, acq_navg = [-5000.0 + 250.0 * i for i in range(41)], 1
+        shard, n_real, width = prn_all, 32, 32
+    else:
+        acq_freqs, acq_navg = [-5000.0 + 50.0 * i for i in range(201)], 10
+        shard, n_real, width = sharding.padded_shard(prn_all, rank, world)
+    cells = len(acq_freqs) * width
+    comm = d_send = d_recv = gathered = lib = None
     use_rccl = world > 1 and not a.rehearse
+    collective = 'none'
     if world > 1:
         import ctypes as C
         from gpsmi import _lib
@@ -258,10 +356,9 @@ def main():
         idb = np.zeros(_lib.COMM_ID_BYTES, np.uint8)
         if rank == 0:
             E.check(lib.gpsmi_comm_unique_id(E.ptr(idb)), 'comm_unique_id')
-        import torch
         tid = torch.from_numpy(idb)
         dist.broadcast(tid, 0)
-        collective = 'rehearsal: none'
+        collective = 'rehearsal: gloo all-gather'
         if use_rccl:
             comm = C.c_void_p()
             rc = lib.gpsmi_comm_create(E.ptr(idb), world, rank, local, C.byref(comm))
@@ -275,14 +372,13 @@ def main():
                 if rc == 0:
                     lib.gpsmi_comm_destroy(comm)
                 comm, use_rccl = None, False
-        cells = len(f41) * len(shard)
         d_send = E.DeviceBuffer(cells * 16, local)
         d_recv = E.DeviceBuffer(cells * 16 * world, local)
         gathered = np.zeros(cells * world, dtype=E.PEAK_DTYPE)
 
     trk.replay_load(nb, states, cl_out['delay_used'])
     # two page-locked result buffers: the read-back of step k overlaps the kernels of step k+1
-    pins = [E.PinnedArray((nb, N_CH), E.OUT_DTYPE) for _ in range(2)]
+    pins = [E.PinnedArray((nb, nch), E.OUT_DTYPE) for _ in range(2)]
 
     def barrier():
         if dist is not None:
@@ -291,27 +387,32 @@ def main():
 
     corr_ms, total_ms, acq_ms = [], [], []
     recording = [False]
-
-    acq_pin = E.PinnedArray((len(f41), len(shard)), E.PEAK_DTYPE)
+    acq_pin = E.PinnedArray((len(acq_freqs), width), E.PEAK_DTYPE)
+    acq_n = acq_navg * 2048
 
     def record_last():
         t, c = trk.last_ms()
         total_ms.append(t)
         corr_ms.append(c)
 
+    def gather_peaks():
+        """all-gather of the (padded, equal-sized) shard tables -> `gathered`"""
+        if use_rccl:
+            E.check(lib.gpsmi_comm_allgather_peaks(comm, d_send.ptr, d_recv.ptr, cells,
+                                                   E.ptr(gathered)), 'allgather')
+        else:                                              # labelled fallback, see `collective`
+            mine = torch.from_numpy(acq_pin.array.view(np.uint8).reshape(-1).copy())
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine)
+            gathered[:] = np.concatenate([p.numpy().view(E.PEAK_DTYPE) for p in parts])
+
     def finish_search():
         """wait for the search enqueued one step ago; gather its peak records"""
         acq.engine.wait()
         if recording[0]:
             acq_ms.append(acq.engine.last_ms())
-        if use_rccl:
-            E.check(lib.gpsmi_comm_allgather_peaks(
-                comm, d_send.ptr, d_recv.ptr, len(f41) * len(shard),
-                E.ptr(gathered)), 'allgather')
-        elif world > 1 and not a.rehearse:                 # labelled fallback, see `collective`
-            mine = torch.from_numpy(acq_pin.array.view(np.uint8).reshape(-1).copy())
-            parts = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(parts, mine)
+        if world > 1:
+            gather_peaks()
 
     def step(k, record):
         # Software pipeline of depth two: the host enqueues step k (search on its own
@@ -324,10 +425,10 @@ def main():
         # beside the code-phase correlation of batch k and is over before the correlator
         # (the kernel the roofline is quoted for) starts
         acq.engine.after(trk)
-        acq.engine.search_async(d_iq.ptr, NGPS, shard, f41, 1, acq_pin.array,
+        acq.engine.search_async(d_iq0.ptr, acq_n, shard, acq_freqs, acq_navg, acq_pin.array,
                                 d_send.ptr if world > 1 else None)
-        # the kernel-timing events are barrier packets in the queue (~5 us each): the
-        # kernels of every fourth step are timed, the others run without them
+        # the kernel-timing events of the other kernels are barrier packets in the queue
+        # (~5 us each): the kernels of every fourth step are timed, the others run without
         trk.set_timing(k % TIMED_EVERY == 0)
         trk.replay_run_async(d_iq.at(trk_base), nb)
         trk.replay_fetch_async(pins[k & 1].array)
@@ -353,7 +454,6 @@ def main():
         record_last()
     trk.set_timing(True)
     if dist is not None:
-        import torch
         tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt[0])
@@ -365,20 +465,65 @@ def main():
                   for k in ('delay', 'freq', 'phase', 'phase_locked', 'nps',
                             'prev_sum_re', 'prev_sum_im', 'df_len'))
     locked = int(cl_out[-1]['phase_locked'].sum())
+    checks = {'replay_equals_closed_loop': bool(same), 'replay_states_chain': bool(chained),
+              'channels_locked_at_end': locked, 'acquired': len(found)}
+    if dist is not None:
+        okt = torch.tensor([1 if (same and chained) else 0])
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        checks['all_ranks_replay_ok'] = bool(int(okt[0]))
+        # the gathered, merged search must equal the unsharded search of the same IQ
+        if rank == 0:
+            tabs = [gathered[r * cells:(r + 1) * cells].reshape(len(acq_freqs), width)
+                    for r in range(world)]
+            merged = sharding.merge_peak_tables(tabs, prn_all, world)
+            full = acq.engine.search((d_iq0.ptr, acq_n), prn_all, acq_freqs, acq_navg)
+            checks['gathered_search_equals_unsharded'] = bool(merged.tobytes() == full.tobytes())
+        if by_channel:                      # channel-sharded outputs, merged in channel order
+            wch = -(-len(chans_all) // world)
+            mine = np.zeros((nb, wch), dtype=E.OUT_DTYPE)
+            mine[:, :len(chans)] = cl_out[:, :len(chans)]
+            send = torch.from_numpy(mine.view(np.uint8).reshape(-1).copy())
+            parts = [torch.empty_like(send) for _ in range(world)]
+            dist.all_gather(parts, send)     # (after the timed region: result check only)
+            if rank == 0:
+                per = [parts[r].numpy().view(E.OUT_DTYPE).reshape(nb, wch)
+                       [:, :len(sharding.shard_channels(len(chans_all), r, world))]
+                       for r in range(world)]
+                merged_out = sharding.merge_channel_outputs(per, len(chans_all), world)
+                checks['merged_channels'] = int((merged_out[-1]['prn'] > 0).sum())
+
+    extra = []
+    if rank == 0 and not a.no_extra:
+        extra.append(measure_cfg4(E, acq, d_iq0.ptr))
+        if world == 1:
+            extra.append(measure_cfg5(E, local))
 
     if rank == 0:
         samples = nb * NGPS
         ms_step = dt / a.steps * 1e3
-        value = samples * world / (dt / a.steps) / 1e6
+        scale = 1 if by_channel else world
+        value = samples * scale / (dt / a.steps) / 1e6
         k_ms = float(np.mean(corr_ms))
         alg_bytes = samples * 8
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic('trk_span_kernel') if nb == 1024 else (None, None)
+        if world == 1:
+            sharding_txt = '1 GPU'
+            acq_txt = 'configs[1]: 32 SV x 41 Doppler x 1 ms acquisition search'
+        else:
+            acq_txt = (f'configs[3]: 32 SV x 201 Doppler x 10 ms acquisition search, SVs sharded '
+                       f'{width} per rank, peaks by {collective}')
+            sharding_txt = (f'{world} ranks: tracking sharded '
+                            + ('by channel (round-robin, every rank reads the same IQ; '
+                               'north_star / reference layout)' if by_channel else
+                               'in time (each rank its own blocks of the stream)')
+                            + f', acquisition sharded by SV, peaks by {collective}')
         line = {
             'metric': 'IQ Msamples/s ingested, 32-SV acq + 12-ch track',
             'value': round(value, 1), 'unit': 'Msamples/s', 'n_gpus': world,
             'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(ms_step, 4), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'scaling': 'strong' if by_channel else 'weak', 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic',
             'config': {
                 'workload': ('BASELINE configs[2]: 12-channel tracking of '
@@ -386,21 +531,21 @@ def main():
                              f'{samples * 8 / 2**20:.0f} MiB resident in HBM) '
                              'in replay of the closed-loop trajectory, results '
                              'copied to host (the copy of a step overlaps the '
-                             'kernels of the next); preceded per step by configs[1]: '
-                             '32 SV x 41 Doppler x 1 ms acquisition search'),
-                'channels': len(chans), 'blocks': nb, 'sample_rate_hz': 2048000,
-                'sharding': ('1 GPU' if world == 1 else
-                             f'{world} ranks: stream sharded in time, '
-                             f'acquisition sharded by SV, peaks by {collective}'),
+                             'kernels of the next); preceded per step by ' + acq_txt),
+                'channels': len(chans_all), 'blocks': nb, 'sample_rate_hz': 2048000,
+                'sharding': sharding_txt,
             },
             'x_realtime': round(value / 2.048, 1),
             'roofline': {
                 'bound': 'hbm', 'kernel': 'trk_span_kernel',
                 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                'traffic': pmc_traffic() if nb == 1024 else None,
+                'traffic': traffic, 'traffic_source': traffic_src,
                 'kernel_ms': round(k_ms, 4),
+                'kernel_ms_source': 'hipExtLaunchKernel begin/end events, mean of the timed steps',
                 'algorithmic_bytes_per_launch': alg_bytes,
+                'frac_vs_measured_copy': round(achieved / HBM_COPY_GBS, 4),
+                'step_hbm_frac': round(alg_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             },
             'kernels_ms': {
                 'tracking_all': round(float(np.mean(total_ms)), 4),
@@ -416,10 +561,8 @@ def main():
                     round(samples / t_closed_with_readback / 1e6, 1),
                 'device_ms_per_block': round(cl_dev_ms / nb, 4),
             },
-            'checks': {'replay_equals_closed_loop': bool(same),
-                       'replay_states_chain': bool(chained),
-                       'channels_locked_at_end': locked,
-                       'acquired': len(found)},
+            'configs': extra,
+            'checks': checks,
             'device': dev_name,
             'setup_s': {'generate_iq': round(t_gen, 2)},
         }
@@ -427,8 +570,9 @@ def main():
             line['cpu_baseline'] = cpu
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + '\n').encode())
-        if not (same and chained):
-            sys.exit('bench: replay does not reproduce the closed loop')
+        if not (same and chained) or checks.get('gathered_search_equals_unsharded') is False \
+                or checks.get('all_ranks_replay_ok') is False:
+            sys.exit('bench: a result check failed: ' + json.dumps(checks))
     for p_ in pins:
         p_.free()
     acq_pin.free()
