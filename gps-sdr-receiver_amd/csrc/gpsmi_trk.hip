@@ -138,50 +138,21 @@ __device__ inline float np_sum_f32(const float* a, int n) {
     return res;
 }
 
-// One wave per job, lane i = prompt dump i.  Element-wise work (windows, |g|,
-// atan, phase unwrapping by a lane prefix sum) is spread over the lanes; the
-// few float32 sums are evaluated redundantly by every lane over small LDS
-// arrays in numpy's own order (np_sum_f32), so the result does not depend on
-// how lanes are scheduled.
-__global__ __launch_bounds__(256) void trk_epilogue_kernel(
-    const gpsmi_trk_state* __restrict__ st_in, gpsmi_trk_state* __restrict__ st_out,
-    const JobMid* __restrict__ mid, const float2* __restrict__ partial, TrkParams P,
-    int njobs, gpsmi_trk_out* __restrict__ out, const float* __restrict__ spanout, int ng_span) {
-    __shared__ float s_mag[4][40], s_dev[4][40], s_real[4][40], s_df[4][GPSMI_MAX_DF];
-    __shared__ float s_hi[4][64], s_lo[4][64];
-    __shared__ float2 s_S[4][GPSMI_MAX_DUMPS];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int job = blockIdx.x * 4 + wave;
-    if (job >= njobs) return;
-    const gpsmi_trk_state& si = st_in[job];
-    gpsmi_trk_state& so = st_out[job];
-    if (!mid[job].active) {
-        if (st_out != st_in) {                       // copy the closed channel's row through
-            const int* a = reinterpret_cast<const int*>(&si);
-            int* b = reinterpret_cast<int*>(&so);
-            for (int i = lane; i < (int)(sizeof(gpsmi_trk_state) / 4); i += 64) b[i] = a[i];
-        }
-        // the record of a closed channel is all-zero (prn = 0); every byte of an open
-        // channel's record is written by the correlation kernel and below, so the result
-        // buffer needs no memset per launch
-        int* z = reinterpret_cast<int*>(&out[job]);
-        for (int i = lane; i < (int)(sizeof(gpsmi_trk_out) / 4); i += 64) z[i] = 0;
-        return;
-    }
-    gpsmi_trk_out& o = out[job];
-    const int d = mid[job].delay_used;
+// The per-job part of a block behind the correlator, one wave, lane i = prompt dump i.
+// Element-wise work (windows, |g|, atan, phase unwrapping by a lane prefix sum) is spread
+// over the lanes; the few float32 sums are evaluated redundantly by every lane over small
+// LDS arrays in numpy's own order (np_sum_f32), so the result does not depend on how lanes
+// are scheduled.  S[0] head, S[q+1] window q, S[nc] tail (global memory or LDS).
+__device__ __forceinline__ void epilogue_job(const gpsmi_trk_state& si, gpsmi_trk_state& so, int d,
+                                             const float2* S, const TrkParams& P, gpsmi_trk_out& o,
+                                             int lane, float* s_mag_w, float* s_dev_w, float* s_real_w,
+                                             float* s_df_w) {
     const int cs = P.cs, nc = P.n_cyc;
-    const float2* S = partial + (size_t)job * (nc + 1);   // S[0] head, S[q+1] window q, S[nc] tail
-    if (spanout) {          // single-block form of the span correlator: its raw sums are added up here
-        span_collect<1>(spanout, ng_span, job / P.nch, job % P.nch, d, mid[job].om, lane, s_hi[wave],
-                        s_lo[wave], s_S[wave]);
-        S = s_S[wave];
-    }
     // scalar state (same address in every lane: one broadcast load each)
     const int nps = si.nps, df_len = si.df_len, was_locked = si.phase_locked;
     const float freq0 = si.freq, phase0 = si.phase, omega0 = si.omega0;
     const float prev_r = si.prev_sum_re, prev_i = si.prev_sum_im;
-    for (int i = lane; i < df_len; i += 64) s_df[wave][i] = si.df[i];
+    for (int i = lane; i < df_len; i += 64) s_df_w[i] = si.df[i];
 
     // ---- prompt dumps: windows of decodeData (gpslib.py:1403-1420, :1440)
     const int n1 = nps + d;
@@ -209,15 +180,15 @@ __global__ __launch_bounds__(256) void trk_epilogue_kernel(
 
     // ---- amplitude statistics (gpslib.py:1186-1187), float32 like numpy
     const float mag = hypotf(gr, gi);
-    if (lane < nd) s_mag[wave][lane] = mag;
+    if (lane < nd) s_mag_w[lane] = mag;
     __builtin_amdgcn_wave_barrier();
-    const float mmean = np_sum_f32(s_mag[wave], nd) / (float)nd;
+    const float mmean = np_sum_f32(s_mag_w, nd) / (float)nd;
     {
         const float e = sub_rn(mag, mmean);
-        if (lane < nd) s_dev[wave][lane] = mul_rn(e, e);
+        if (lane < nd) s_dev_w[lane] = mul_rn(e, e);
     }
     __builtin_amdgcn_wave_barrier();
-    const float sdev = sqrtf(np_sum_f32(s_dev[wave], nd) / (float)nd);
+    const float sdev = sqrtf(np_sum_f32(s_dev_w, nd) / (float)nd);
 
     // ---- phaseLockedLoop (gpslib.py:1215-1262): unwrap by a lane prefix sum
     const float ph = atanf(gi / gr);
@@ -233,21 +204,21 @@ __global__ __launch_bounds__(256) void trk_epilogue_kernel(
         if (lane >= o2) jump += v;
     }
     const float real = (lane == 0) ? ph : add_rn(ph, mul_rn(jump, kPiF));
-    if (lane < nd) s_real[wave][lane] = real;
+    if (lane < nd) s_real_w[lane] = real;
     __builtin_amdgcn_wave_barrier();
-    const float offset = np_sum_f32(s_real[wave] + (nd - 4), 4) / 4.0f;
-    const float pdev = np_sum_f32(s_real[wave], nd) / (float)nd;
+    const float offset = np_sum_f32(s_real_w + (nd - 4), 4) / 4.0f;
+    const float pdev = np_sum_f32(s_real_w, nd) / (float)nd;
     const float max_df = 20.0f / (float)P.df_no;
     int locked = was_locked;
     int new_len;
     float df;
     if (locked) {
-        const float mean_df = np_sum_f32(s_df[wave], df_len) / (float)df_len;
+        const float mean_df = np_sum_f32(s_df_w, df_len) / (float)df_len;
         df = add_rn(pdev, mean_df);                 // DF_GAIN2 = 1
         if (fabsf(df) > max_df) df = (df > 0.f ? 1.f : -1.f) * max_df;
         const int shift = df_len >= P.df_no ? 1 : 0;   // drop the oldest entry
         new_len = df_len - shift + 1;
-        for (int i = lane; i < new_len - 1; i += 64) so.df[i] = s_df[wave][i + shift];
+        for (int i = lane; i < new_len - 1; i += 64) so.df[i] = s_df_w[i + shift];
         if (lane == 0) so.df[new_len - 1] = df;
     } else {
         df = mul_rn(10.0f, pdev);                   // DF_GAIN1 = 10
@@ -290,6 +261,70 @@ __global__ __launch_bounds__(256) void trk_epilogue_kernel(
         o.nps = nps_new;
         o.reserved1 = 0;
     }
+}
+
+// a closed channel: its state row is copied through, its record is all-zero (prn = 0); every
+// byte of an open channel's record is written by the correlation kernel and epilogue_job, so
+// the result buffer needs no memset per launch
+__device__ __forceinline__ void epilogue_closed(const gpsmi_trk_state& si, gpsmi_trk_state& so,
+                                                gpsmi_trk_out& out, bool copy, int lane) {
+    if (copy) {
+        const int* a = reinterpret_cast<const int*>(&si);
+        int* b = reinterpret_cast<int*>(&so);
+        for (int i = lane; i < (int)(sizeof(gpsmi_trk_state) / 4); i += 64) b[i] = a[i];
+    }
+    int* z = reinterpret_cast<int*>(&out);
+    for (int i = lane; i < (int)(sizeof(gpsmi_trk_out) / 4); i += 64) z[i] = 0;
+}
+
+// One wave per job (four jobs per workgroup): the batch form.
+__global__ __launch_bounds__(256) void trk_epilogue_kernel(
+    const gpsmi_trk_state* __restrict__ st_in, gpsmi_trk_state* __restrict__ st_out,
+    const JobMid* __restrict__ mid, const float2* __restrict__ partial, TrkParams P,
+    int njobs, gpsmi_trk_out* __restrict__ out) {
+    __shared__ float s_mag[4][40], s_dev[4][40], s_real[4][40], s_df[4][GPSMI_MAX_DF];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int job = blockIdx.x * 4 + wave;
+    if (job >= njobs) return;
+    if (!mid[job].active) {
+        epilogue_closed(st_in[job], st_out[job], out[job], st_out != st_in, lane);
+        return;
+    }
+    epilogue_job(st_in[job], st_out[job], mid[job].delay_used, partial + (size_t)job * (P.n_cyc + 1), P,
+                 out[job], lane, s_mag[wave], s_dev[wave], s_real[wave], s_df[wave]);
+}
+
+// One workgroup per job: behind the single-block form of the span correlator (the closed
+// loop).  The four waves add up the spans of one quarter each (independent loads, issued
+// together), wave 0 adds the quarters in their fixed order, forms the windows and runs the
+// per-job part.
+__global__ __launch_bounds__(256) void trk_epilogue_span_kernel(
+    const gpsmi_trk_state* __restrict__ st_in, gpsmi_trk_state* __restrict__ st_out,
+    const JobMid* __restrict__ mid, const float* __restrict__ rec, int ng_span, TrkParams P,
+    int njobs, gpsmi_trk_out* __restrict__ out) {
+    __shared__ float s_mag[40], s_dev[40], s_real[40], s_df[GPSMI_MAX_DF];
+    __shared__ float q_hi[4][64], q_lo[4][64], s_hi[64], s_lo[64];
+    __shared__ float2 s_S[GPSMI_MAX_DUMPS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int job = blockIdx.x;
+    const JobMid md = mid[job];
+    if (!md.active) {
+        if (wave == 0) epilogue_closed(st_in[job], st_out[job], out[job], st_out != st_in, lane);
+        return;
+    }
+    span_collect_quarter<1>(rec, ng_span, job / P.nch, job % P.nch, md.delay_used, lane, wave,
+                            q_hi[wave][lane], q_lo[wave][lane]);
+    __syncthreads();
+    if (wave != 0) return;
+    float h = 0.f, l = 0.f;
+#pragma unroll
+    for (int Q = 0; Q < 4; ++Q) { h += q_hi[Q][lane]; l += q_lo[Q][lane]; }
+    s_hi[lane] = h;
+    s_lo[lane] = l;
+    __builtin_amdgcn_wave_barrier();
+    span_windows(s_hi, s_lo, md.om, lane, s_S);
+    __builtin_amdgcn_wave_barrier();
+    epilogue_job(st_in[job], st_out[job], md.delay_used, s_S, P, out[job], lane, s_mag, s_dev, s_real, s_df);
 }
 
 }  // namespace gpsmi
@@ -426,7 +461,8 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const float2* d_iq,
         // channels per correlation workgroup: fewer channels = fewer live accumulators
         // = more workgroups per CU for the barrier-heavy FFT phase (GPSMI_CORR_CG to tune)
         // (a single block, the closed loop, is latency-bound: spread it over more CUs)
-        const int cg = nblocks * ((nch + h->corr_cg - 1) / h->corr_cg) < 64 ? 2 : h->corr_cg;
+        const int cg = nblocks * ((nch + h->corr_cg - 1) / h->corr_cg) < 64 ? (nblocks * nch <= 64 ? 1 : 2)
+                                                                             : h->corr_cg;
         const int ng = (nch + cg - 1) / cg;
         const dim3 cgrid(((nblocks + 7) / 8) * 8 * ng);
         if (cg == 6)
@@ -435,8 +471,11 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const float2* d_iq,
         else if (cg == 4)
             hipLaunchKernelGGL(trk_corr_kernel<4>, cgrid, dim3(256), 0, h->stream, d_iq, st_in, forced,
                                h->d_rep, h->d_tw, P, ng, nblocks, sl.d_out, h->d_mid);
-        else
+        else if (cg == 2)
             hipLaunchKernelGGL(trk_corr_kernel<2>, cgrid, dim3(256), 0, h->stream, d_iq, st_in, forced,
+                               h->d_rep, h->d_tw, P, ng, nblocks, sl.d_out, h->d_mid);
+        else
+            hipLaunchKernelGGL(trk_corr_kernel<1>, cgrid, dim3(256), 0, h->stream, d_iq, st_in, forced,
                                h->d_rep, h->d_tw, P, ng, nblocks, sl.d_out, h->d_mid);
     }
     // ---- the correlator.  When a launch is timed, the two events of the batch form of the span
@@ -510,9 +549,12 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const float2* d_iq,
 #undef GPSMI_LAUNCH_LDS
     }
     if (timed && !ext_timed) GPSMI_HIP(hipEventRecord(sl.ev[2], h->stream));
-    hipLaunchKernelGGL(trk_epilogue_kernel, dim3((njobs + 3) / 4), dim3(256), 0, h->stream, st_in,
-                       st_out, h->d_mid, h->d_partial, P, njobs, sl.d_out,
-                       span_single ? h->d_rec : (const float*)nullptr, ng_span);
+    if (span_single)
+        hipLaunchKernelGGL(trk_epilogue_span_kernel, dim3(njobs), dim3(256), 0, h->stream, st_in, st_out,
+                           h->d_mid, h->d_rec, ng_span, P, njobs, sl.d_out);
+    else
+        hipLaunchKernelGGL(trk_epilogue_kernel, dim3((njobs + 3) / 4), dim3(256), 0, h->stream, st_in,
+                           st_out, h->d_mid, h->d_partial, P, njobs, sl.d_out);
     GPSMI_HIP(hipGetLastError());
     if (timed) GPSMI_HIP(hipEventRecord(sl.ev[3], h->stream));
     return GPSMI_OK;

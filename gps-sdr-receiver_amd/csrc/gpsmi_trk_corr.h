@@ -1,6 +1,6 @@
 // Code-phase correlation of the tracking loop: cacodeCorr + findCodePhase +
 // fitCodePhase (reference src/gpslib.py:1315-1327, :1293-1304, :1268-1290) for
-// up to CG (2, 4 or 6) channels of one block per workgroup.
+// up to CG (1, 2, 4 or 6) channels of one block per workgroup.
 //
 // The reference wipes the carrier off the centre corr_avg code periods, sums
 // their FFTs, multiplies by conj(FFT(replica)) and takes |ifft|.  Here the sum
@@ -96,10 +96,15 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(
 #pragma unroll
         for (int c = 0; c < CG; ++c) u[c] = v2f{urow[c][i].x, urow[c][i].y};
 #pragma unroll
-        for (int r = 0; r < 8; ++r)
+        for (int r = 0; r < 8; ++r) {
+            if (CG == 1) {                       // (cmac2 works on pairs: two positions at once)
+                if (r & 1) cmac2(acc[0][r - 1], acc[0][r], u[0], x[r - 1], u[0], x[r]);
+            } else {
 #pragma unroll
-            for (int c = 0; c < CG; c += 2)
-                cmac2(acc[c][r], acc[c + 1][r], u[c], x[r], u[c + 1], x[r]);
+                for (int c = 0; c + 1 < CG; c += 2)
+                    cmac2(acc[c][r], acc[c + 1][r], u[c], x[r], u[c + 1], x[r]);
+            }
+        }
     }
 
     // ---- per channel: apply V, FFT, x conj(R), FFT, statistics

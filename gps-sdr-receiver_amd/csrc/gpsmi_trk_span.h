@@ -534,58 +534,74 @@ __global__ __launch_bounds__(64 * WAVES, 2) void trk_span_kernel(
     }
 }
 
-// One wave per job: the sums of the ranges of channel `cidx` of block `b` -> S[0 .. 32]
-// (= what the other correlators write to partial[job][.]) in LDS.  lane = (row, re/im);
-// hi / lo: 64 floats of LDS each.  NSPANS = spans per record, as the kernel that wrote them.
+// The sums of quarter Q of channel `cidx` of block `b`, for lane = (row, re/im): what the
+// quarter contributes to the hi and to the lo side of the delay `d`.  NSPANS = spans per record,
+// as the kernel that wrote them.  (Loads first, then the adds in the fixed order.)
 template <int NSPANS>
-__device__ __forceinline__ void span_collect(const float* __restrict__ rec, int ngroups, int b, int cidx,
-                                             int d, float om, int lane, float* hi, float* lo, float2* S) {
-    constexpr int NC = 32;
+__device__ __forceinline__ void span_collect_quarter(const float* __restrict__ rec, int ngroups, int b,
+                                                     int cidx, int d, int lane, int Q, float& w_hi,
+                                                     float& w_lo) {
     constexpr int kPerQ = kSpQuarter / (NSPANS * kSpTile);   // records per quarter: 1 or 8
     constexpr int kLen = NSPANS * kSpTile;                   // positions per record
     const int g = cidx / kSpCh, cc = cidx % kSpCh;
     const int r = lane >> 1, part = lane & 1;
     const int n = cc >> 3, j = 2 * (cc & 7) + part, mt = r >> 4, rg = (r & 15) >> 2, v = r & 3;
-    const float* src = rec + (size_t)(b * ngroups + g) * (4 * kPerQ) * kSpRecFloats
+    const float* src = rec + ((size_t)(b * ngroups + g) * (4 * kPerQ) + (size_t)kPerQ * Q) * kSpRecFloats
                        + ((mt * 2 + n) * 4 + v) * 64 + 16 * rg + j;
-    float h = 0.f, l = 0.f;
+    const int rel = d - Q * kSpQuarter;
+    const bool all_lo = rel >= kSpQuarter;
+    const int pb = (rel > 0 && rel < kSpQuarter) ? rel : kSpInf;
+    float t[kPerQ], lf = 0.f;
 #pragma unroll
-    for (int Q = 0; Q < 4; ++Q) {
-        const int rel = d - Q * kSpQuarter;
-        const bool all_lo = rel >= kSpQuarter;
-        const int pb = (rel > 0 && rel < kSpQuarter) ? rel : kSpInf;
-        float T = 0.f, L = 0.f;
+    for (int s = 0; s < kPerQ; ++s) t[s] = src[(size_t)s * kSpRecFloats];
+    if (pb != kSpInf && pb % kLen != 0) lf = src[(size_t)(pb / kLen) * kSpRecFloats + kSpLoOfs];
+    float T = 0.f, L = 0.f;
+    if (kPerQ == 1) {
+        // the wave that summed the quarter closed lo itself where the boundary passed
+        T = t[0];
+        L = (pb != kSpInf) ? lf : 0.f;
+    } else {
 #pragma unroll
         for (int s = 0; s < kPerQ; ++s) {
-            const float* p = src + (size_t)(kPerQ * Q + s) * kSpRecFloats;
-            const float t = p[0];
-            if (kPerQ == 1) {
-                // the wave that summed the quarter closed lo itself where the boundary passed
-                T = t;
-                if (pb != kSpInf) L = p[kSpLoOfs];
-            } else {
-                if (pb > s * kLen && pb < (s + 1) * kLen) {        // closed inside this range
-                    L = T + p[kSpLoOfs];
-                    T = 0.f;
-                } else if (pb == s * kLen) {                       // ... exactly at its start
-                    L = T + 0.f;
-                    T = 0.f;
-                }
-                T = T + t;
+            if (pb >= s * kLen && pb < (s + 1) * kLen) {       // lo closes in (or exactly at the start of) this span
+                L = T + (pb == s * kLen ? 0.f : lf);
+                T = 0.f;
             }
+            T = T + t[s];
         }
-        h += all_lo ? 0.f : T;
-        l += all_lo ? T : L;
     }
-    hi[lane] = h;
-    lo[lane] = l;
-    __builtin_amdgcn_wave_barrier();
+    w_hi = all_lo ? 0.f : T;
+    w_lo = all_lo ? T : L;
+}
+
+// hi / lo (64 floats of LDS each, lane = (row, re/im)) -> S[0 .. 32] = what the other
+// correlators write to partial[job][.]; one wave
+__device__ __forceinline__ void span_windows(const float* hi, const float* lo, float om, int lane, float2* S) {
+    constexpr int NC = 32;
     if (lane <= NC) {
         const int q = lane - 1;
         const float hx = q >= 0 ? hi[2 * q] : 0.f, hy = q >= 0 ? hi[2 * q + 1] : 0.f;
         const float lx = q + 1 < NC ? lo[2 * (q + 1)] : 0.f, ly = q + 1 < NC ? lo[2 * (q + 1) + 1] : 0.f;
         S[lane] = sp_window(hx, hy, lx, ly, sp_row_factor(om, q), sp_row_factor(om, q + 1));
     }
+}
+
+// One wave per job: the four quarters in turn, then the windows.
+template <int NSPANS>
+__device__ __forceinline__ void span_collect(const float* __restrict__ rec, int ngroups, int b, int cidx,
+                                             int d, float om, int lane, float* hi, float* lo, float2* S) {
+    float h = 0.f, l = 0.f;
+#pragma unroll
+    for (int Q = 0; Q < 4; ++Q) {
+        float wh, wl;
+        span_collect_quarter<NSPANS>(rec, ngroups, b, cidx, d, lane, Q, wh, wl);
+        h += wh;
+        l += wl;
+    }
+    hi[lane] = h;
+    lo[lane] = l;
+    __builtin_amdgcn_wave_barrier();
+    span_windows(hi, lo, om, lane, S);
     __builtin_amdgcn_wave_barrier();
 }
 
