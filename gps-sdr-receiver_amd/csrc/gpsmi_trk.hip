@@ -56,7 +56,7 @@ struct TrkParams {
     float t_last;      // SEC_TIME[NGPS-1]
     float om_min, om_max;   // float32(2*pi*MIN_FREQ), float32(2*pi*MAX_FREQ) from float64
     int flags;              // diagnostics only (GPSMI_DEBUG_FLAGS): 1 no MAC, 2 no lane sums, 4 no mixed fix,
-                            // 8 LDS-ring correlator
+                            // 8 LDS-ring correlator, 16 the timed span correlator launch is a repeat
 };
 
 // per-job descriptor handed from the correlation kernel to the correlator and
@@ -336,13 +336,18 @@ struct gpsmi_trk {
     int max_ch = 0;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;   // result read-back, overlaps the next replay run
+    hipStream_t epi_stream = nullptr;    // replay: the epilogue of run k beside the code-phase
+                                         // correlation of run k + 1 (the other slot's buffers)
     hipEvent_t order = nullptr;          // orders other handles' streams behind this one
     // two result slots: a replay run writes one while the other is still being copied out
     struct Slot {
         gpsmi_trk_out* d_out = nullptr;
         hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // start, corr done, correlator done, end
         hipEvent_t ready = nullptr, copied = nullptr;
-        bool copy_pending = false, timing_pending = false;
+        hipEvent_t corr_done = nullptr, epi_done = nullptr;   // correlator / epilogue of the slot's run
+        bool copy_pending = false, timing_pending = false, epi_pending = false;
+        JobMid* d_mid = nullptr;             // per-job descriptors and window sums of the slot's run
+        float2* d_partial = nullptr;
     } slot[2];
     int cur = 0;                         // slot of the latest launch
     bool timing = true;                  // record the four kernel-timing events per launch
@@ -361,8 +366,6 @@ struct gpsmi_trk {
     gpsmi_trk_state* d_tab_in = nullptr;
     gpsmi_trk_state* d_tab_out = nullptr;
     int* d_forced = nullptr;
-    JobMid* d_mid = nullptr;
-    float2* d_partial = nullptr;
     float last_total_ms = 0.f, last_corr_ms = 0.f;
     int replay_nb = 0;
     bool replay_forced = false;
@@ -377,6 +380,7 @@ struct gpsmi_trk {
     float* d_code_eo = nullptr;      // [GPSMI_MAX_PRN + 1][2][cs]: replica split by index parity, each
                                      // plane twice (span form)
     float* d_rec = nullptr;          // raw sums of the span correlator's waves (gpsmi_trk_span.h)
+    int n_cu = 256;                  // compute units of the device
     int nchunks = 1;                 // spans of 256 * stream_j positions per code period
     float2* d_fold = nullptr; float* d_mag = nullptr; DirStats* d_stats = nullptr;
     int* d_xsel = nullptr; int* d_rsel = nullptr; float2* d_partial_g = nullptr;
@@ -389,13 +393,14 @@ constexpr int kSpanUnitsMax = 16;    // (block, channel group) pairs the single-
 
 static int trk_reserve(gpsmi_trk* h, size_t njobs) {
     if (njobs <= h->njobs_cap) return GPSMI_OK;
-    void* olds[] = {h->d_tab_in, h->d_tab_out, h->d_forced, h->d_mid, h->d_partial, h->slot[0].d_out,
-                    h->slot[1].d_out,
+    void* olds[] = {h->d_tab_in, h->d_tab_out, h->d_forced, h->slot[0].d_mid, h->slot[1].d_mid,
+                    h->slot[0].d_partial, h->slot[1].d_partial, h->slot[0].d_out, h->slot[1].d_out,
                     h->d_fold, h->d_mag, h->d_stats, h->d_xsel, h->d_rsel, h->d_partial_g, h->d_rec};
     for (void* p : olds)
         if (p) GPSMI_HIP(hipFree(p));
-    h->d_tab_in = h->d_tab_out = nullptr; h->d_forced = nullptr; h->d_mid = nullptr;
-    h->d_partial = nullptr; h->slot[0].d_out = h->slot[1].d_out = nullptr; h->njobs_cap = 0;
+    h->d_tab_in = h->d_tab_out = nullptr; h->d_forced = nullptr;
+    for (auto& sl : h->slot) { sl.d_mid = nullptr; sl.d_partial = nullptr; sl.d_out = nullptr; }
+    h->njobs_cap = 0;
     h->d_fold = nullptr; h->d_mag = nullptr; h->d_stats = nullptr; h->d_xsel = h->d_rsel = nullptr;
     h->d_partial_g = nullptr; h->d_rec = nullptr;
     if (h->mfma == 4) {     // 32 records per (block, channel group) of the single-block span form
@@ -417,9 +422,11 @@ static int trk_reserve(gpsmi_trk* h, size_t njobs) {
     GPSMI_HIP(hipMalloc((void**)&h->d_tab_in, njobs * sizeof(gpsmi_trk_state)));
     GPSMI_HIP(hipMalloc((void**)&h->d_tab_out, njobs * sizeof(gpsmi_trk_state)));
     GPSMI_HIP(hipMalloc((void**)&h->d_forced, njobs * sizeof(int)));
-    GPSMI_HIP(hipMalloc((void**)&h->d_mid, njobs * sizeof(JobMid)));
-    GPSMI_HIP(hipMalloc((void**)&h->d_partial, njobs * (h->cfg.n_cyc + 1) * sizeof(float2)));
-    for (auto& sl : h->slot) GPSMI_HIP(hipMalloc((void**)&sl.d_out, njobs * sizeof(gpsmi_trk_out)));
+    for (auto& sl : h->slot) {
+        GPSMI_HIP(hipMalloc((void**)&sl.d_mid, njobs * sizeof(JobMid)));
+        GPSMI_HIP(hipMalloc((void**)&sl.d_partial, njobs * (h->cfg.n_cyc + 1) * sizeof(float2)));
+        GPSMI_HIP(hipMalloc((void**)&sl.d_out, njobs * sizeof(gpsmi_trk_out)));
+    }
     h->njobs_cap = njobs;
     return GPSMI_OK;
 }
@@ -427,7 +434,7 @@ static int trk_reserve(gpsmi_trk* h, size_t njobs) {
 // the three kernels over njobs jobs on the handle's stream, events around them
 static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const float2* d_iq,
                       const gpsmi_trk_state* st_in, gpsmi_trk_state* st_out, const int* forced,
-                      int njobs, int nch) {
+                      int njobs, int nch, bool side_epilogue = false) {
     TrkParams P = h->P;
     P.nch = nch;
     const bool timed = h->timing;        // each event record is a barrier packet (~5 us of bubble)
@@ -444,7 +451,7 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const float2* d_iq,
         const int cs = P.cs;
         hipLaunchKernelGGL(trk_fold_general_kernel, dim3((cs + 255) / 256, njobs), dim3(256), 0,
                            h->stream, d_iq, h->d_t32, st_in, P, h->d_fold, h->d_xsel, h->d_rsel,
-                           h->d_mid);
+                           sl.d_mid);
         if (h->big)
             big_corr_launch(h->stream, h->d_fold, h->d_xsel, h->d_rsel, njobs, cs, h->d_RS, h->d_S,
                             h->d_tw, h->d_twN, h->d_mag);
@@ -456,7 +463,7 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const float2* d_iq,
         hipLaunchKernelGGL(corr_stats_kernel, dim3(njobs), dim3(256), 0, h->stream, h->d_mag, cs,
                            h->d_stats);
         hipLaunchKernelGGL(trk_decide_kernel, dim3((njobs + 255) / 256), dim3(256), 0, h->stream,
-                           h->d_stats, forced, P, njobs, sl.d_out, h->d_mid);
+                           h->d_stats, forced, P, njobs, sl.d_out, sl.d_mid);
     } else {
         // channels per correlation workgroup: fewer channels = fewer live accumulators
         // = more workgroups per CU for the barrier-heavy FFT phase (GPSMI_CORR_CG to tune)
@@ -467,48 +474,59 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const float2* d_iq,
         const dim3 cgrid(((nblocks + 7) / 8) * 8 * ng);
         if (cg == 6)
             hipLaunchKernelGGL(trk_corr_kernel<6>, cgrid, dim3(256), 0, h->stream, d_iq, st_in, forced,
-                               h->d_rep, h->d_tw, P, ng, nblocks, sl.d_out, h->d_mid);
+                               h->d_rep, h->d_tw, P, ng, nblocks, sl.d_out, sl.d_mid);
         else if (cg == 4)
             hipLaunchKernelGGL(trk_corr_kernel<4>, cgrid, dim3(256), 0, h->stream, d_iq, st_in, forced,
-                               h->d_rep, h->d_tw, P, ng, nblocks, sl.d_out, h->d_mid);
+                               h->d_rep, h->d_tw, P, ng, nblocks, sl.d_out, sl.d_mid);
         else if (cg == 2)
             hipLaunchKernelGGL(trk_corr_kernel<2>, cgrid, dim3(256), 0, h->stream, d_iq, st_in, forced,
-                               h->d_rep, h->d_tw, P, ng, nblocks, sl.d_out, h->d_mid);
+                               h->d_rep, h->d_tw, P, ng, nblocks, sl.d_out, sl.d_mid);
         else
             hipLaunchKernelGGL(trk_corr_kernel<1>, cgrid, dim3(256), 0, h->stream, d_iq, st_in, forced,
-                               h->d_rep, h->d_tw, P, ng, nblocks, sl.d_out, h->d_mid);
+                               h->d_rep, h->d_tw, P, ng, nblocks, sl.d_out, sl.d_mid);
     }
     // ---- the correlator.  When a launch is timed, the two events of the batch form of the span
     // correlator are the dispatch's own begin / end stamps (hipExtLaunchKernel: what a kernel
     // trace reports), not event records around it: no barrier packets next to the kernel and
     // no launch gap inside the pair.
     const bool ext_timed = timed && h->mfma == 4 && !span_single;
+    // batch form of the span correlator: persistent workgroups, two per CU, an equal number of
+    // (block, channel group) units each
+    const int span_units = nblocks * ng_span, span_slots = 2 * h->n_cu;
+    const int span_per = (span_units + span_slots - 1) / span_slots;
+    const dim3 span_grid((span_units + span_per - 1) / (span_per > 0 ? span_per : 1));
     if (timed && !ext_timed) GPSMI_HIP(hipEventRecord(sl.ev[1], h->stream));
     if (h->mfma) {                         // the correlator on the matrix pipe
         const int ng12 = (nch + kMfCh - 1) / kMfCh;
         const dim3 mgrid(((nblocks + 7) / 8) * 8 * ng12);
         if (h->mfma == 4 && span_single)
             hipLaunchKernelGGL((trk_span_kernel<1, 1>), dim3(nblocks * ng12 * 32), dim3(64), 0, h->stream,
-                               d_iq, h->d_mid, h->d_code_eo, P, ng12, nblocks, h->d_rec, h->d_partial);
-        else if (h->mfma == 4 && ext_timed)
-            hipExtLaunchKernelGGL((trk_span_kernel<8, 4>), dim3(nblocks * ng12), dim3(256), 0, h->stream,
-                                  sl.ev[1], sl.ev[2], 0, d_iq, (const JobMid*)h->d_mid,
-                                  (const float*)h->d_code_eo, P, ng12, nblocks, h->d_rec, h->d_partial);
+                               d_iq, sl.d_mid, h->d_code_eo, P, ng12, nblocks, h->d_rec, sl.d_partial);
+        else if (h->mfma == 4 && ext_timed && (P.flags & 16)) {   // diagnostics: the timed launch is a second one
+            hipLaunchKernelGGL((trk_span_kernel<8, 4>), span_grid, dim3(256), 0, h->stream,
+                               d_iq, sl.d_mid, h->d_code_eo, P, ng12, nblocks, h->d_rec, sl.d_partial);
+            hipExtLaunchKernelGGL((trk_span_kernel<8, 4>), span_grid, dim3(256), 0, h->stream,
+                                  sl.ev[1], sl.ev[2], 0, d_iq, (const JobMid*)sl.d_mid,
+                                  (const float*)h->d_code_eo, P, ng12, nblocks, h->d_rec, sl.d_partial);
+        } else if (h->mfma == 4 && ext_timed)
+            hipExtLaunchKernelGGL((trk_span_kernel<8, 4>), span_grid, dim3(256), 0, h->stream,
+                                  sl.ev[1], sl.ev[2], 0, d_iq, (const JobMid*)sl.d_mid,
+                                  (const float*)h->d_code_eo, P, ng12, nblocks, h->d_rec, sl.d_partial);
         else if (h->mfma == 4)
-            hipLaunchKernelGGL((trk_span_kernel<8, 4>), dim3(nblocks * ng12), dim3(256), 0, h->stream,
-                               d_iq, h->d_mid, h->d_code_eo, P, ng12, nblocks, h->d_rec, h->d_partial);
+            hipLaunchKernelGGL((trk_span_kernel<8, 4>), span_grid, dim3(256), 0, h->stream,
+                               d_iq, sl.d_mid, h->d_code_eo, P, ng12, nblocks, h->d_rec, sl.d_partial);
         else if (h->mfma != 1)
             hipLaunchKernelGGL(trk_stream_mfma_kernel<4>, mgrid, dim3(256), 0, h->stream, d_iq,
-                               h->d_mid, h->d_code2, P, ng12, nblocks, h->d_partial);
+                               sl.d_mid, h->d_code2, P, ng12, nblocks, sl.d_partial);
         else
             hipLaunchKernelGGL(trk_stream_mfma_kernel<8>, mgrid, dim3(512), 0, h->stream, d_iq,
-                               h->d_mid, h->d_code2, P, ng12, nblocks, h->d_partial);
+                               sl.d_mid, h->d_code2, P, ng12, nblocks, sl.d_partial);
     } else if (!(P.flags & 8) || h->general) {    // default: the register-staged correlator
         const dim3 grid(sgrid.x, h->nchunks), block(kStreamThreads);
-        float2* pdst = h->nchunks > 1 ? h->d_partial_g : h->d_partial;
+        float2* pdst = h->nchunks > 1 ? h->d_partial_g : sl.d_partial;
 #define GPSMI_LAUNCH_STREAM(NC, POW2, J)                                                        \
     hipLaunchKernelGGL((trk_stream_kernel<NC, POW2, J>), grid, block, 0, h->stream, d_iq, st_in, \
-                       h->d_mid, h->d_code, P, ngroups, nblocks, pdst)
+                       sl.d_mid, h->d_code, P, ngroups, nblocks, pdst)
 #define GPSMI_LAUNCH_STREAM_NC(POW2, J)                 \
     do {                                                \
         if (P.n_cyc == 32) GPSMI_LAUNCH_STREAM(32, POW2, J);      \
@@ -528,13 +546,13 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const float2* d_iq,
             const int per_job = P.n_cyc + 1;
             hipLaunchKernelGGL(trk_partial_reduce_kernel, dim3((njobs * per_job + 255) / 256),
                                dim3(256), 0, h->stream, h->d_partial_g, h->nchunks, per_job, njobs,
-                               h->d_mid, h->d_partial);
+                               sl.d_mid, sl.d_partial);
         }
     } else {                               // GPSMI_DEBUG_FLAGS=8: the LDS-ring variant
 #define GPSMI_LAUNCH_LDS(NC, G)                                                                 \
     hipLaunchKernelGGL((trk_stream_lds_kernel<NC, G>), dim3(nblocks* nsuper), dim3(256 * G), 0, \
-                       h->stream, d_iq, st_in, h->d_mid, h->d_code, P, nsuper, nblocks,          \
-                       h->d_partial)
+                       h->stream, d_iq, st_in, sl.d_mid, h->d_code, P, nsuper, nblocks,          \
+                       sl.d_partial)
         const int G = nch > kGroupCh ? 2 : 1;
         const int nsuper = (nch + kGroupCh * G - 1) / (kGroupCh * G);
         if (G == 2) {
@@ -549,14 +567,26 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const float2* d_iq,
 #undef GPSMI_LAUNCH_LDS
     }
     if (timed && !ext_timed) GPSMI_HIP(hipEventRecord(sl.ev[2], h->stream));
+    // replay: the epilogue goes to a stream of its own behind the correlator, so that the
+    // code-phase correlation of the next run (other slot, main stream) starts at once
+    hipStream_t es = h->stream;
+    if (side_epilogue) {
+        es = h->epi_stream;
+        GPSMI_HIP(hipEventRecord(sl.corr_done, h->stream));
+        GPSMI_HIP(hipStreamWaitEvent(es, sl.corr_done, 0));
+    }
     if (span_single)
-        hipLaunchKernelGGL(trk_epilogue_span_kernel, dim3(njobs), dim3(256), 0, h->stream, st_in, st_out,
-                           h->d_mid, h->d_rec, ng_span, P, njobs, sl.d_out);
+        hipLaunchKernelGGL(trk_epilogue_span_kernel, dim3(njobs), dim3(256), 0, es, st_in, st_out,
+                           sl.d_mid, h->d_rec, ng_span, P, njobs, sl.d_out);
     else
-        hipLaunchKernelGGL(trk_epilogue_kernel, dim3((njobs + 3) / 4), dim3(256), 0, h->stream, st_in,
-                           st_out, h->d_mid, h->d_partial, P, njobs, sl.d_out);
+        hipLaunchKernelGGL(trk_epilogue_kernel, dim3((njobs + 3) / 4), dim3(256), 0, es, st_in,
+                           st_out, sl.d_mid, sl.d_partial, P, njobs, sl.d_out);
     GPSMI_HIP(hipGetLastError());
-    if (timed) GPSMI_HIP(hipEventRecord(sl.ev[3], h->stream));
+    if (timed) GPSMI_HIP(hipEventRecord(sl.ev[3], es));
+    if (side_epilogue) {
+        GPSMI_HIP(hipEventRecord(sl.epi_done, es));
+        sl.epi_pending = true;
+    }
     return GPSMI_OK;
 }
 
@@ -577,6 +607,8 @@ static int trk_take_timing(gpsmi_trk* h, gpsmi_trk::Slot& sl) {
 // everything enqueued so far (kernels and read-backs) has finished
 static int trk_settle(gpsmi_trk* h) {
     GPSMI_HIP(hipStreamSynchronize(h->stream));
+    GPSMI_HIP(hipStreamSynchronize(h->epi_stream));
+    h->slot[0].epi_pending = h->slot[1].epi_pending = false;
     if (h->slot[0].copy_pending || h->slot[1].copy_pending)
         GPSMI_HIP(hipStreamSynchronize(h->copy_stream));
     for (int k = 0; k < 2; ++k) {          // older slot first: last_*_ms end up with the latest run
@@ -643,13 +675,17 @@ int gpsmi_trk_create(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk** out) {
 }  // extern "C"
 
 static int trk_build(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk* h) {
+    GPSMI_HIP(hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, cfg->device));
     GPSMI_HIP(hipStreamCreate(&h->stream));
     GPSMI_HIP(hipStreamCreate(&h->copy_stream));
+    GPSMI_HIP(hipStreamCreate(&h->epi_stream));
     GPSMI_HIP(hipEventCreateWithFlags(&h->order, hipEventDisableTiming));
     for (auto& sl : h->slot) {
         for (auto& e : sl.ev) GPSMI_HIP(hipEventCreate(&e));
         GPSMI_HIP(hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming));
         GPSMI_HIP(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
+        GPSMI_HIP(hipEventCreateWithFlags(&sl.corr_done, hipEventDisableTiming));
+        GPSMI_HIP(hipEventCreateWithFlags(&sl.epi_done, hipEventDisableTiming));
     }
     std::vector<float2> tw;
     make_twiddles(tw);
@@ -723,8 +759,10 @@ int gpsmi_trk_destroy(gpsmi_trk* h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
+    if (h->epi_stream) (void)hipStreamSynchronize(h->epi_stream);
     void* bufs[] = {h->d_tw, h->d_t32, h->d_rep, h->d_code, h->d_block, h->d_state, h->d_tab_in,
-                    h->d_tab_out, h->d_forced, h->d_mid, h->d_partial, h->slot[0].d_out,
+                    h->d_tab_out, h->d_forced, h->slot[0].d_mid, h->slot[1].d_mid, h->slot[0].d_partial,
+                    h->slot[1].d_partial, h->slot[0].d_out,
                     h->slot[1].d_out, h->d_fold,
                     h->d_mag, h->d_stats, h->d_xsel, h->d_rsel, h->d_partial_g, h->d_twN, h->d_RS,
                     h->d_S, h->d_code2, h->d_code_eo, h->d_rec};
@@ -735,9 +773,12 @@ int gpsmi_trk_destroy(gpsmi_trk* h) {
             if (e) (void)hipEventDestroy(e);
         if (sl.ready) (void)hipEventDestroy(sl.ready);
         if (sl.copied) (void)hipEventDestroy(sl.copied);
+        if (sl.corr_done) (void)hipEventDestroy(sl.corr_done);
+        if (sl.epi_done) (void)hipEventDestroy(sl.epi_done);
     }
     if (h->order) (void)hipEventDestroy(h->order);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+    if (h->epi_stream) (void)hipStreamDestroy(h->epi_stream);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return GPSMI_OK;
@@ -849,7 +890,8 @@ int gpsmi_trk_process_dev(gpsmi_trk* h, const void* d_iq, size_t n, gpsmi_trk_ou
     int rc = trk_push_state(h);
     if (rc) return rc;
     if (h->slot[0].copy_pending || h->slot[1].copy_pending || h->slot[0].timing_pending ||
-        h->slot[1].timing_pending) {       // a replay still in flight owns the slots
+        h->slot[1].timing_pending || h->slot[0].epi_pending ||
+        h->slot[1].epi_pending) {          // a replay still in flight owns the slots
         rc = trk_settle(h);
         if (rc) return rc;
     }
@@ -923,9 +965,13 @@ int gpsmi_trk_replay_run_async(gpsmi_trk* h, const void* d_iq, int nb) {
         GPSMI_HIP(hipStreamWaitEvent(h->stream, sl.copied, 0));
         sl.copy_pending = false;
     }
+    if (sl.epi_pending) {                  // ... and the epilogue that read its buffers be done
+        GPSMI_HIP(hipStreamWaitEvent(h->stream, sl.epi_done, 0));
+        sl.epi_pending = false;
+    }
     sl.timing_pending = h->timing;
     return trk_launch(h, sl, (const float2*)d_iq, h->d_tab_in, h->d_tab_out,
-                      h->replay_forced ? h->d_forced : nullptr, nb * nch, nch);
+                      h->replay_forced ? h->d_forced : nullptr, nb * nch, nch, /*side_epilogue=*/true);
 }
 
 int gpsmi_trk_wait(gpsmi_trk* h) {
@@ -960,8 +1006,12 @@ int gpsmi_trk_replay_fetch_async(gpsmi_trk* h, gpsmi_trk_out* out, size_t n) {
     gpsmi_trk::Slot& sl = h->slot[h->cur];
     // the copy runs on its own stream behind the run that produced the records, so the
     // next run (other slot) overlaps it
-    GPSMI_HIP(hipEventRecord(sl.ready, h->stream));
-    GPSMI_HIP(hipStreamWaitEvent(h->copy_stream, sl.ready, 0));
+    if (sl.epi_pending) {                  // the records are complete when the slot's epilogue is
+        GPSMI_HIP(hipStreamWaitEvent(h->copy_stream, sl.epi_done, 0));
+    } else {
+        GPSMI_HIP(hipEventRecord(sl.ready, h->stream));
+        GPSMI_HIP(hipStreamWaitEvent(h->copy_stream, sl.ready, 0));
+    }
     GPSMI_HIP(hipMemcpyAsync(out, sl.d_out, n * sizeof(gpsmi_trk_out), hipMemcpyDeviceToHost,
                              h->copy_stream));
     GPSMI_HIP(hipEventRecord(sl.copied, h->copy_stream));

@@ -138,37 +138,66 @@ __device__ __forceinline__ int sp_wave_min(int v) {
     return __builtin_amdgcn_readfirstlane(v);
 }
 
-// One wave: NSPANS consecutive spans starting at position `pos0` (a multiple of 64) of a
-// block.  Returns the sums of the range for [M tile][N tile] in (tot, lo_fin): lo_fin = what
-// was summed below the delay when the boundary lies inside the range, tot = the rest.
-// (DIAG, probes only: 1 no MFMAs, 2 no row loads after the first tile)
-// (DIAG 8: row loads with the default cache policy instead of non-temporal)
-template <int NSPANS, int DIAG = 0>
-__device__ __forceinline__ void span_wave(const float2* __restrict__ blk, float* tl, float* cd,
-                                          const JobMid* __restrict__ midrow, int nch_g,
-                                          const float* __restrict__ code_eo, int pos0, int lane,
-                                          sp4 (&tot)[2][2], sp4 (&lo_fin)[2][2], bool (&all_lo)[2],
-                                          int (&pb)[2]) {
-    constexpr int CS = kFftN, NC = 32;
-    const int j = lane & 15, k = lane >> 4, pi = k >> 1, kap = k & 1, part = j & 1;
-    const int q0 = pos0 & ~(kSpQuarter - 1);                      // start of the quarter
-    constexpr int kTiles = NSPANS;
+// what a wave needs of a job descriptor
+struct SpDesc {
+    int delay_used, active, prn;
+    float om, ph;
+};
+__device__ __forceinline__ SpDesc sp_desc(const JobMid* __restrict__ midrow, int c, bool have) {
+    const JobMid m = midrow[have ? c : 0];
+    SpDesc d;
+    d.delay_used = m.delay_used; d.active = have && m.active; d.prn = m.prn; d.om = m.om; d.ph = m.ph;
+    return d;
+}
+// the descriptors of a wave's lane roles: its two channels (one per N tile) and, for the lanes
+// that stage the replica (l < 48), the channel l / 4
+__device__ __forceinline__ void sp_wave_descs(const JobMid* __restrict__ midrow, int nch_g, int lane,
+                                              SpDesc (&md)[2], SpDesc& smd) {
+    const int j = lane & 15;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int c = 8 * n + (j >> 1);
+        md[n] = sp_desc(midrow, c, c < kSpCh && c < nch_g);
+    }
+    const int sc = lane >> 2;
+    smd = sp_desc(midrow, sc, lane < 4 * kSpCh && sc < nch_g);
+}
 
-    // ---- tile staging: 16 x b128 per lane; instruction i covers rows 2 i, 2 i + 1 (lane / 32)
-    // and 512 bytes of each.  Global address = scalar base + one lane offset (buffer loads).
-    // The rows are read once: non-temporal loads (3 % faster than the default policy).
+// ---- tile staging: 16 x b128 per lane; instruction i covers rows 2 i, 2 i + 1 (lane / 32) and
+// 512 bytes of each.  Global address = scalar base + one lane offset (buffer loads; a tile
+// position past the block reads nothing and returns zeros).  The rows are read once:
+// non-temporal loads (3 % faster than the default policy).
+template <int AUX = 2>
+__device__ __forceinline__ void sp_load_tile(const float2* blk, int pos, int lane, sp4 (&st)[16]) {
+    constexpr int CS = kFftN, NC = 32;
     const __amdgpu_buffer_rsrc_t blk_rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float2*>(blk), 0, CS * NC * (int)sizeof(float2), kMfRsrcFlags);
     const int ld_off = ((lane >> 5) * CS + 2 * (lane & 31)) * (int)sizeof(float2);
-    float* st_dst = tl + (lane >> 5) * kSpRowDw + 4 * (lane & 31);
-    sp4 st[16];
-    auto load_tile = [&](int tix) {
-        const int tb = (pos0 + tix * kSpTile) * (int)sizeof(float2);
+    const int tb = pos * (int)sizeof(float2);
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-            st[i] = __builtin_bit_cast(sp4, __builtin_amdgcn_raw_buffer_load_b128(
-                blk_rs, ld_off, tb + i * (2 * CS * (int)sizeof(float2)), (DIAG & 8) ? 0 : 2));
-    };
+    for (int i = 0; i < 16; ++i)
+        st[i] = __builtin_bit_cast(sp4, __builtin_amdgcn_raw_buffer_load_b128(
+            blk_rs, ld_off, tb + i * (2 * CS * (int)sizeof(float2)), AUX));
+}
+
+// One wave: NSPANS consecutive spans starting at position `pos0` (a multiple of 64) of a
+// block.  The caller has requested the first tile into `st` (sp_load_tile) and fetched the
+// descriptors; on return `st` holds the request for the tile at `next_pos` of `next_blk` (the
+// first tile of the wave's next range, or a position past the block: nothing).  Returns the
+// sums of the range for [M tile][N tile] in (tot, lo_fin): lo_fin = what was summed below the
+// delay when the boundary lies inside the range, tot = the rest.
+// (DIAG, probes only: 1 no MFMAs, 2 no row loads after the first tile, 8 default cache policy)
+template <int NSPANS, int DIAG = 0>
+__device__ __forceinline__ void span_wave(const float2* __restrict__ blk, const float2* next_blk,
+                                          int next_pos, float* tl, float* cd, const SpDesc (&mdd)[2],
+                                          const SpDesc& smd, const float* __restrict__ code_eo,
+                                          int pos0, int lane, sp4 (&st)[16], sp4 (&tot)[2][2],
+                                          sp4 (&lo_fin)[2][2], bool (&all_lo)[2], int (&pb)[2]) {
+    constexpr int CS = kFftN;
+    const int j = lane & 15, k = lane >> 4, pi = k >> 1, kap = k & 1, part = j & 1;
+    const int q0 = pos0 & ~(kSpQuarter - 1);                      // start of the quarter
+    constexpr int kTiles = NSPANS;
+    float* st_dst = tl + (lane >> 5) * kSpRowDw + 4 * (lane & 31);
     auto store_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {                 // rows are 8-byte aligned: two b64 writes
@@ -176,7 +205,6 @@ __device__ __forceinline__ void span_wave(const float2* __restrict__ blk, float*
             *reinterpret_cast<sp2*>(st_dst + i * 2 * kSpRowDw + 2) = sp2{st[i].z, st[i].w};
         }
     };
-    load_tile(0);                     // requested before anything that depends on the descriptors
 
     // ---- lane roles: two channels (one per N tile); the recurrence of both, seeded with the
     // exact phasor of the lane's first two positions of the QUARTER
@@ -191,9 +219,8 @@ __device__ __forceinline__ void span_wave(const float2* __restrict__ blk, float*
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int c = 8 * n + (j >> 1);
-        const bool col = c < kSpCh && c < nch_g;
-        const JobMid md = midrow[col ? c : 0];
-        const bool active = col && md.active;
+        const SpDesc& md = mdd[n];
+        const bool active = md.active;
         const float f_eff = active ? (float)((double)md.om * inv_2pi) : 0.f;
         const float ph_rev = active ? md.ph * (float)inv_2pi : 0.f;
         const float2 w2 = sp_phasor_rev(2.0f * (f_eff * inv_fs));      // exp(-j 2 phi)
@@ -224,9 +251,7 @@ __device__ __forceinline__ void span_wave(const float2* __restrict__ blk, float*
     // half index (r - e) / 2, which advances by one per pair: a contiguous run of the table
     // plane e (doubled, so the run never wraps).  A closed channel reads PRN slot 0 (zeros).
     const int sc = lane >> 2, spl = (lane >> 1) & 1, shf = lane & 1;
-    const bool s_on = lane < 4 * kSpCh && sc < nch_g;
-    const JobMid smd = midrow[s_on ? sc : 0];
-    const bool s_act = s_on && smd.active;
+    const bool s_act = smd.active;
     const __amdgpu_buffer_rsrc_t code_rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(code_eo), 0, (GPSMI_MAX_PRN + 1) * 2 * CS * (int)sizeof(float), kMfRsrcFlags);
     int sc_off;
@@ -282,11 +307,16 @@ __device__ __forceinline__ void span_wave(const float2* __restrict__ blk, float*
     for (int tix = 0; tix < kTiles; ++tix) {
         // the tile that waited in registers goes to LDS (the reads of the previous one are
         // behind us: LDS serves a wave in order), then the tile after it is requested
-        // (unconditional: past the end the last tile is fetched again and never used)
+        // (unconditional: behind the last tile of the range it is the first one of the wave's
+        // next range, or a position past the block, which costs no memory traffic)
         store_code();
         store_tile();
         load_code(2 * tix + 1);
-        if (!(DIAG & 2)) load_tile(tix + 1 < kTiles ? tix + 1 : kTiles - 1);
+        if (!(DIAG & 2)) {
+            const bool more = tix + 1 < kTiles;            // else: the first tile of the wave's next range
+            sp_load_tile<(DIAG & 8) ? 0 : 2>(more ? blk : next_blk, more ? pos0 + (tix + 1) * kSpTile : next_pos,
+                                             lane, st);
+        }
         __builtin_amdgcn_sched_barrier(0);
         const int tpos = rel0 + tix * kSpTile;                       // tile start within the quarter
 
@@ -405,8 +435,11 @@ __device__ __forceinline__ void span_wave(const float2* __restrict__ blk, float*
 //   batch form:        range = quarter; the four quarters of a block are the four waves of
 //                      one workgroup (so the four 4 KiB pieces of every 16 KiB row are
 //                      requested together).  The waves leave their hi / lo row sums in LDS;
-//                      behind the one barrier of the kernel all threads add the quarters in
-//                      their fixed order and write partial[job][.] (3 KiB per block).
+//                      behind a barrier all threads add the quarters in their fixed order and
+//                      write partial[job][.] (3 KiB per block).  The workgroups are
+//                      persistent (two per CU, each takes every gridDim-th block): the
+//                      first rows and the descriptors of the next block are requested before
+//                      the combine step of the current one.
 //                      Measured instead, per 1024-block launch: the wave that arrives last
 //                      combines alone, the others exit without a barrier +6 us (the
 //                      workgroup's LDS is held until that wave is done); one-wave workgroups
@@ -430,42 +463,32 @@ __global__ __launch_bounds__(64 * WAVES, 2) void trk_span_kernel(
     constexpr int kRanges = CS / (NSPANS * kSpTile);    // per block: 4 quarters or 32 spans
     constexpr bool kWholeBlock = kRanges == WAVES;      // the workgroup holds all ranges of its block
     static_assert(kRanges % WAVES == 0, "the waves of a workgroup share a block");
+    constexpr int kNowhere = CS * NC;                   // a tile position past the block: reads nothing
     __shared__ __attribute__((aligned(16))) float lds[WAVES][kSpWaveFloats];
+    __shared__ float4 ufac[kWholeBlock ? kSpCh * (NC + 1) : 1];      // (U[q], U[q+1]); .w = NaN: channel closed
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int widx = blockIdx.x * WAVES + wave;
-    const int unit = widx / kRanges, range = widx % kRanges;
-    const int g = unit % ngroups, b = unit / ngroups;
-    if (b >= nblocks) return;
-    // for the combine step at the end: which partial[q + 1] this thread writes; its channel's
-    // descriptor is fetched now, so that no memory round trip is left on the tail of the block
-    constexpr int kItems = kWholeBlock ? (kSpCh * (NC + 1) + 64 * WAVES - 1) / (64 * WAVES) : 1;
-    bool on[kItems];
-    float om_item[kItems];
-    if (kWholeBlock) {
-#pragma unroll
-        for (int e = 0; e < kItems; ++e) {
-            const int item = (int)threadIdx.x + 64 * WAVES * e;
-            const int ci = g * kSpCh + item / (NC + 1);
-            on[e] = item < kSpCh * (NC + 1) && ci < P.nch;
-            const JobMid m2 = mid[b * P.nch + (on[e] ? ci : 0)];
-            on[e] = on[e] && m2.active;
-            om_item[e] = m2.om;
-        }
-    }
-    const float2* blk = iq + (size_t)b * ((size_t)CS * NC);
+    const int nunits = nblocks * ngroups;
     float* tl = &lds[wave][0];
-    sp4 tot[2][2], lo_fin[2][2];
+    sp4 st[16], tot[2][2], lo_fin[2][2];
     bool all_lo[2];
     int pb[2];
-    span_wave<NSPANS, DIAG>(blk, tl, tl + kSpTileFloats, mid + (size_t)b * P.nch + g * kSpCh,
-                            P.nch - g * kSpCh, code_eo, range * NSPANS * kSpTile, lane, tot, lo_fin, all_lo, pb);
-    if (DIAG & 4) {
-        if (tot[0][0][0] + tot[1][1][1] + lo_fin[0][1][2] + lo_fin[1][0][3] != 123.456f) return;
-    }
+    SpDesc md[2], smd;
+
     if (!kWholeBlock) {
+        // ---- single-block form: one span per wave, raw sums to `rec`
+        const int widx = blockIdx.x * WAVES + wave;
+        const int unit = widx / kRanges, range = widx % kRanges;
+        if (unit >= nunits) return;
+        const int g = unit % ngroups, b = unit / ngroups;
+        const float2* blk = iq + (size_t)b * ((size_t)CS * NC);
+        const int pos0 = range * NSPANS * kSpTile;
+        sp_load_tile<(DIAG & 8) ? 0 : 2>(blk, pos0, lane, st);   // before anything that depends on the descriptors
+        sp_wave_descs(mid + (size_t)b * P.nch + g * kSpCh, P.nch - g * kSpCh, lane, md, smd);
+        span_wave<NSPANS, DIAG>(blk, blk, kNowhere, tl, tl + kSpTileFloats, md, smd, code_eo, pos0, lane, st, tot,
+                                lo_fin, all_lo, pb);
         float* o = rec + ((size_t)unit * kRanges + range) * kSpRecFloats + lane;
-        const int rel0 = (range * NSPANS * kSpTile) & (kSpQuarter - 1);
+        const int rel0 = pos0 & (kSpQuarter - 1);
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             const bool closed = pb[n] > rel0 && pb[n] < rel0 + NSPANS * kSpTile;   // lo was closed in this range
@@ -479,58 +502,121 @@ __global__ __launch_bounds__(64 * WAVES, 2) void trk_span_kernel(
         }
         return;
     }
-    // ---- whole block in the workgroup: hi / lo sums of every row of the quarter into LDS
-    // (the wave's own tile area), D[i = 4 (lane / 16) + v][j = lane % 16]; behind one barrier
-    // all threads add the quarters in their fixed order, apply U and write partial[q + 1],
-    // q = -1 .. 31
+
+    // ---- batch form: the workgroup takes units blockIdx.x, blockIdx.x + gridDim.x, ...; the
+    // first rows and the descriptors of the next unit are requested before the combine step of
+    // the current one, so only the first unit of a workgroup waits for memory at its start
     constexpr int kSumFloats = kSpCh * NC * 2;          // [channel][row][re, im]
     static_assert(2 * kSumFloats <= kSpTileFloats, "row sums must fit the tile area");
+    constexpr int kItems = (kSpCh * (NC + 1) + 64 * WAVES - 1) / (64 * WAVES);
+    int unit = blockIdx.x;
+    if (unit >= nunits) return;
+    const int pos0 = wave * kSpQuarter;
+    // for the combine step: which partial[q + 1] a thread writes, whether its channel is open
+    // and the row factors U[q], U[q+1].  The descriptor is fetched with the unit's others, the
+    // factors (double arithmetic) are formed at the start of the unit and wait in LDS: nothing
+    // of this stays in registers across the tile loop or is left for the tail of the block
+    bool on[kItems];
+    float om_item[kItems];
+    auto fetch_items = [&](int u) {
+        const int g = u % ngroups, b = u / ngroups;
+#pragma unroll
+        for (int e = 0; e < kItems; ++e) {
+            const int item = (int)threadIdx.x + 64 * WAVES * e;
+            const int ci = g * kSpCh + item / (NC + 1);
+            on[e] = item < kSpCh * (NC + 1) && ci < P.nch;
+            const JobMid m2 = mid[b * P.nch + (on[e] ? ci : 0)];
+            on[e] = on[e] && m2.active;
+            om_item[e] = m2.om;
+        }
+    };
+    auto park_items = [&]() {
+#pragma unroll
+        for (int e = 0; e < kItems; ++e) {
+            const int item = (int)threadIdx.x + 64 * WAVES * e;
+            if (item >= kSpCh * (NC + 1)) continue;
+            const int q = item % (NC + 1) - 1;
+            const float2 a0 = sp_row_factor(om_item[e], q), a1 = sp_row_factor(om_item[e], q + 1);
+            ufac[item] = make_float4(a0.x, a0.y, a1.x, on[e] ? a1.y : __builtin_nanf(""));
+        }
+    };
     {
-        float* hi = tl;
-        float* lo = tl + kSumFloats;
-        const int j = lane & 15, part = j & 1;
+        const int g = unit % ngroups, b = unit / ngroups;
+        sp_load_tile<(DIAG & 8) ? 0 : 2>(iq + (size_t)b * ((size_t)CS * NC), pos0, lane, st);
+        sp_wave_descs(mid + (size_t)b * P.nch + g * kSpCh, P.nch - g * kSpCh, lane, md, smd);
+        fetch_items(unit);
+    }
+#pragma unroll 1
+    for (;;) {
+        const int g = unit % ngroups, b = unit / ngroups;
+        park_items();
+        // (the lane-derived constants of a wave's set-up are recomputed per unit instead of
+        // being carried through the tile loop in registers the loop needs)
+        int lane_u = lane;
+        asm volatile("" : "+v"(lane_u));
+        const float2* blk = iq + (size_t)b * ((size_t)CS * NC);
+        const int next = unit + (int)gridDim.x;
+        const bool has_next = next < nunits;
+        const float2* next_blk = has_next ? iq + (size_t)(next / ngroups) * ((size_t)CS * NC) : blk;
+        span_wave<NSPANS, DIAG>(blk, next_blk, has_next ? pos0 : kNowhere, tl, tl + kSpTileFloats, md, smd, code_eo,
+                                pos0, lane_u, st, tot, lo_fin, all_lo, pb);
+        // the hi / lo sums of every row of the quarter into LDS (the wave's own tile area),
+        // D[i = 4 (lane / 16) + v][j = lane % 16]
+        if (!(DIAG & 4)) {
+            float* hi = tl;
+            float* lo = tl + kSumFloats;
+            const int j = lane & 15, part = j & 1;
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const int c = 8 * n + (j >> 1);
-            const sp4 z = sp4{0.f, 0.f, 0.f, 0.f};
+            for (int n = 0; n < 2; ++n) {
+                const int c = 8 * n + (j >> 1);
+                const sp4 z = sp4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const sp4 w_hi = all_lo[n] ? z : tot[mt][n];
-                const sp4 w_lo = all_lo[n] ? tot[mt][n] : lo_fin[mt][n];
-                if (c < kSpCh) {
+                for (int mt = 0; mt < 2; ++mt) {
+                    const sp4 w_hi = all_lo[n] ? z : tot[mt][n];
+                    const sp4 w_lo = all_lo[n] ? tot[mt][n] : lo_fin[mt][n];
+                    if (c < kSpCh) {
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const int row = 16 * mt + 4 * (lane >> 4) + v;
-                        hi[(c * NC + row) * 2 + part] = w_hi[v];
-                        lo[(c * NC + row) * 2 + part] = w_lo[v];
+                        for (int v = 0; v < 4; ++v) {
+                            const int row = 16 * mt + 4 * (lane >> 4) + v;
+                            hi[(c * NC + row) * 2 + part] = w_hi[v];
+                            lo[(c * NC + row) * 2 + part] = w_lo[v];
+                        }
                     }
                 }
             }
         }
-    }
-    // the row factors (double arithmetic) before the barrier, the sums behind it
-    float2 u0[kItems], u1[kItems];
-#pragma unroll
-    for (int e = 0; e < kItems; ++e) {
-        const int q = ((int)threadIdx.x + 64 * WAVES * e) % (NC + 1) - 1;
-        u0[e] = sp_row_factor(om_item[e], q);
-        u1[e] = sp_row_factor(om_item[e], q + 1);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < kItems; ++e) {
-        if (!on[e]) continue;
-        const int item = (int)threadIdx.x + 64 * WAVES * e;
-        const int cc = item / (NC + 1), o = item % (NC + 1), q = o - 1;
-        float hx = 0.f, hy = 0.f, lx = 0.f, ly = 0.f;
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) {
-            const float* hi = &lds[w][0];
-            const float* lo = hi + kSumFloats;
-            if (q >= 0) { hx += hi[(cc * NC + q) * 2]; hy += hi[(cc * NC + q) * 2 + 1]; }
-            if (q + 1 < NC) { lx += lo[(cc * NC + q + 1) * 2]; ly += lo[(cc * NC + q + 1) * 2 + 1]; }
+        // the descriptors of the next unit on their way while the quarters are combined
+        if (has_next) {
+            sp_wave_descs(mid + (size_t)(next / ngroups) * P.nch + (next % ngroups) * kSpCh,
+                          P.nch - (next % ngroups) * kSpCh, lane, md, smd);
+            fetch_items(next);
         }
-        partial[((size_t)b * P.nch + g * kSpCh + cc) * (NC + 1) + o] = sp_window(hx, hy, lx, ly, u0[e], u1[e]);
+        if (!(DIAG & 4)) {
+            // behind one barrier all threads add the quarters in their fixed order, apply U and
+            // write partial[q + 1], q = -1 .. 31
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < kItems; ++e) {
+                const int item = (int)threadIdx.x + 64 * WAVES * e;
+                if (item >= kSpCh * (NC + 1)) continue;
+                const float4 uf = ufac[item];
+                if (uf.w != uf.w) continue;                 // closed channel
+                const int cc = item / (NC + 1), o = item % (NC + 1), q = o - 1;
+                float hx = 0.f, hy = 0.f, lx = 0.f, ly = 0.f;
+#pragma unroll
+                for (int w = 0; w < WAVES; ++w) {
+                    const float* hi = &lds[w][0];
+                    const float* lo = hi + kSumFloats;
+                    if (q >= 0) { hx += hi[(cc * NC + q) * 2]; hy += hi[(cc * NC + q) * 2 + 1]; }
+                    if (q + 1 < NC) { lx += lo[(cc * NC + q + 1) * 2]; ly += lo[(cc * NC + q + 1) * 2 + 1]; }
+                }
+                partial[((size_t)b * P.nch + g * kSpCh + cc) * (NC + 1) + o] =
+                    sp_window(hx, hy, lx, ly, make_float2(uf.x, uf.y), make_float2(uf.z, uf.w));
+            }
+        }
+        if (!has_next) break;
+        if (!(DIAG & 4)) __syncthreads();               // the tile areas are free again
+        unit = next;
     }
 }
 

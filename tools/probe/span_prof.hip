@@ -44,6 +44,8 @@ struct Bufs {
     float2* iq; JobMid* mid; float* code2; float* code_eo; float2* partial; float* rec; double* ref;
 };
 
+static int g_slots = 512;          // workgroups of the batch form the chip holds (2 per CU)
+
 // what the epilogue kernel does with the records: one wave per job -> partial[job][0 .. 32]
 template <int NSP>
 __global__ void collect_kernel(const float* rec, const JobMid* mid, int ngroups, int nch, int njobs,
@@ -62,8 +64,13 @@ static void launch_span_t(const Bufs& B, int nblocks, int nch, bool collect) {
     TrkParams P{};
     P.cs = 2048; P.n_cyc = 32; P.nch = nch;
     const int ng = (nch + kSpCh - 1) / kSpCh;
-    hipLaunchKernelGGL((trk_span_kernel<NSP, WAVES, DIAG>), dim3(nblocks * ng * (32 / NSP) / WAVES),
-                       dim3(64 * WAVES), 0, 0, B.iq, B.mid, B.code_eo, P, ng, nblocks, B.rec, B.partial);
+    int grid = nblocks * ng * (32 / NSP) / WAVES;
+    if (NSP * WAVES == 32) {                       // batch form: persistent workgroups, two per CU
+        const int per = (grid + g_slots - 1) / g_slots;
+        grid = (grid + per - 1) / per;
+    }
+    hipLaunchKernelGGL((trk_span_kernel<NSP, WAVES, DIAG>), dim3(grid), dim3(64 * WAVES), 0, 0, B.iq, B.mid,
+                       B.code_eo, P, ng, nblocks, B.rec, B.partial);
     if (collect && NSP * WAVES != 32)
         hipLaunchKernelGGL(collect_kernel<NSP>, dim3((nblocks * nch + 3) / 4), dim3(256), 0, 0, B.rec, B.mid, ng,
                            nch, nblocks * nch, B.partial);
@@ -209,6 +216,7 @@ static void set_delays(Bufs& B, int nblocks, int nch, int mode) {
 
 int main(int argc, char** argv) {
     const int nblocks = argc > 1 ? atoi(argv[1]) : 1024, nch = 12;
+    if (argc > 2) g_slots = atoi(argv[2]);
     const size_t blk = (size_t)2048 * 32;
     Bufs B{};
     hipMalloc((void**)&B.iq, nblocks * blk * sizeof(float2));
