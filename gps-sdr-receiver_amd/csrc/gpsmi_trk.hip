@@ -381,6 +381,7 @@ struct gpsmi_trk {
                                      // plane twice (span form)
     float* d_rec = nullptr;          // raw sums of the span correlator's waves (gpsmi_trk_span.h)
     int n_cu = 256;                  // compute units of the device
+    int iq_fmt = GPSMI_IQ_C64;       // what the iq pointers of process / replay point to
     int nchunks = 1;                 // spans of 256 * stream_j positions per code period
     float2* d_fold = nullptr; float* d_mag = nullptr; DirStats* d_stats = nullptr;
     int* d_xsel = nullptr; int* d_rsel = nullptr; float2* d_partial_g = nullptr;
@@ -432,11 +433,13 @@ static int trk_reserve(gpsmi_trk* h, size_t njobs) {
 }
 
 // the three kernels over njobs jobs on the handle's stream, events around them
-static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const float2* d_iq,
+static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
                       const gpsmi_trk_state* st_in, gpsmi_trk_state* st_out, const int* forced,
                       int njobs, int nch, bool side_epilogue = false) {
     TrkParams P = h->P;
     P.nch = nch;
+    const float2* d_iq = static_cast<const float2*>(d_iq_v);       // (raw uint16 when iq_fmt says so)
+    const bool u8 = h->iq_fmt == GPSMI_IQ_U8;
     const bool timed = h->timing;        // each event record is a barrier packet (~5 us of bubble)
     if (timed) GPSMI_HIP(hipEventRecord(sl.ev[0], h->stream));
     const int nblocks = njobs / nch;
@@ -472,18 +475,20 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const float2* d_iq,
                                                                              : h->corr_cg;
         const int ng = (nch + cg - 1) / cg;
         const dim3 cgrid(((nblocks + 7) / 8) * 8 * ng);
-        if (cg == 6)
-            hipLaunchKernelGGL(trk_corr_kernel<6>, cgrid, dim3(256), 0, h->stream, d_iq, st_in, forced,
-                               h->d_rep, h->d_tw, P, ng, nblocks, sl.d_out, sl.d_mid);
-        else if (cg == 4)
-            hipLaunchKernelGGL(trk_corr_kernel<4>, cgrid, dim3(256), 0, h->stream, d_iq, st_in, forced,
-                               h->d_rep, h->d_tw, P, ng, nblocks, sl.d_out, sl.d_mid);
-        else if (cg == 2)
-            hipLaunchKernelGGL(trk_corr_kernel<2>, cgrid, dim3(256), 0, h->stream, d_iq, st_in, forced,
-                               h->d_rep, h->d_tw, P, ng, nblocks, sl.d_out, sl.d_mid);
-        else
-            hipLaunchKernelGGL(trk_corr_kernel<1>, cgrid, dim3(256), 0, h->stream, d_iq, st_in, forced,
-                               h->d_rep, h->d_tw, P, ng, nblocks, sl.d_out, sl.d_mid);
+#define GPSMI_LAUNCH_CORR(CGV)                                                                          \
+    do {                                                                                              \
+        if (u8)                                                                                       \
+            hipLaunchKernelGGL((trk_corr_kernel<CGV, 1>), cgrid, dim3(256), 0, h->stream, d_iq_v,     \
+                               st_in, forced, h->d_rep, h->d_tw, P, ng, nblocks, sl.d_out, sl.d_mid); \
+        else                                                                                          \
+            hipLaunchKernelGGL((trk_corr_kernel<CGV, 0>), cgrid, dim3(256), 0, h->stream, d_iq_v,     \
+                               st_in, forced, h->d_rep, h->d_tw, P, ng, nblocks, sl.d_out, sl.d_mid); \
+    } while (0)
+        if (cg == 6) GPSMI_LAUNCH_CORR(6);
+        else if (cg == 4) GPSMI_LAUNCH_CORR(4);
+        else if (cg == 2) GPSMI_LAUNCH_CORR(2);
+        else GPSMI_LAUNCH_CORR(1);
+#undef GPSMI_LAUNCH_CORR
     }
     // ---- the correlator.  When a launch is timed, the two events of the batch form of the span
     // correlator are the dispatch's own begin / end stamps (hipExtLaunchKernel: what a kernel
@@ -499,22 +504,32 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const float2* d_iq,
     if (h->mfma) {                         // the correlator on the matrix pipe
         const int ng12 = (nch + kMfCh - 1) / kMfCh;
         const dim3 mgrid(((nblocks + 7) / 8) * 8 * ng12);
-        if (h->mfma == 4 && span_single)
-            hipLaunchKernelGGL((trk_span_kernel<1, 1>), dim3(nblocks * ng12 * 32), dim3(64), 0, h->stream,
-                               d_iq, sl.d_mid, h->d_code_eo, P, ng12, nblocks, h->d_rec, sl.d_partial);
+        if (h->mfma == 4 && span_single && u8)
+            hipLaunchKernelGGL((trk_span_kernel<1, 1, 0, 1>), dim3(nblocks * ng12 * 32), dim3(64), 0, h->stream,
+                               d_iq_v, sl.d_mid, h->d_code_eo, P, ng12, nblocks, h->d_rec, sl.d_partial);
+        else if (h->mfma == 4 && span_single)
+            hipLaunchKernelGGL((trk_span_kernel<1, 1, 0, 0>), dim3(nblocks * ng12 * 32), dim3(64), 0, h->stream,
+                               d_iq_v, sl.d_mid, h->d_code_eo, P, ng12, nblocks, h->d_rec, sl.d_partial);
         else if (h->mfma == 4 && ext_timed && (P.flags & 16)) {   // diagnostics: the timed launch is a second one
-            hipLaunchKernelGGL((trk_span_kernel<8, 4>), span_grid, dim3(256), 0, h->stream,
-                               d_iq, sl.d_mid, h->d_code_eo, P, ng12, nblocks, h->d_rec, sl.d_partial);
-            hipExtLaunchKernelGGL((trk_span_kernel<8, 4>), span_grid, dim3(256), 0, h->stream,
-                                  sl.ev[1], sl.ev[2], 0, d_iq, (const JobMid*)sl.d_mid,
+            hipLaunchKernelGGL((trk_span_kernel<8, 4, 0, 0>), span_grid, dim3(256), 0, h->stream,
+                               d_iq_v, sl.d_mid, h->d_code_eo, P, ng12, nblocks, h->d_rec, sl.d_partial);
+            hipExtLaunchKernelGGL((trk_span_kernel<8, 4, 0, 0>), span_grid, dim3(256), 0, h->stream,
+                                  sl.ev[1], sl.ev[2], 0, d_iq_v, (const JobMid*)sl.d_mid,
                                   (const float*)h->d_code_eo, P, ng12, nblocks, h->d_rec, sl.d_partial);
-        } else if (h->mfma == 4 && ext_timed)
-            hipExtLaunchKernelGGL((trk_span_kernel<8, 4>), span_grid, dim3(256), 0, h->stream,
-                                  sl.ev[1], sl.ev[2], 0, d_iq, (const JobMid*)sl.d_mid,
+        } else if (h->mfma == 4 && ext_timed && u8)
+            hipExtLaunchKernelGGL((trk_span_kernel<8, 4, 0, 1>), span_grid, dim3(256), 0, h->stream,
+                                  sl.ev[1], sl.ev[2], 0, d_iq_v, (const JobMid*)sl.d_mid,
                                   (const float*)h->d_code_eo, P, ng12, nblocks, h->d_rec, sl.d_partial);
+        else if (h->mfma == 4 && ext_timed)
+            hipExtLaunchKernelGGL((trk_span_kernel<8, 4, 0, 0>), span_grid, dim3(256), 0, h->stream,
+                                  sl.ev[1], sl.ev[2], 0, d_iq_v, (const JobMid*)sl.d_mid,
+                                  (const float*)h->d_code_eo, P, ng12, nblocks, h->d_rec, sl.d_partial);
+        else if (h->mfma == 4 && u8)
+            hipLaunchKernelGGL((trk_span_kernel<8, 4, 0, 1>), span_grid, dim3(256), 0, h->stream,
+                               d_iq_v, sl.d_mid, h->d_code_eo, P, ng12, nblocks, h->d_rec, sl.d_partial);
         else if (h->mfma == 4)
-            hipLaunchKernelGGL((trk_span_kernel<8, 4>), span_grid, dim3(256), 0, h->stream,
-                               d_iq, sl.d_mid, h->d_code_eo, P, ng12, nblocks, h->d_rec, sl.d_partial);
+            hipLaunchKernelGGL((trk_span_kernel<8, 4, 0, 0>), span_grid, dim3(256), 0, h->stream,
+                               d_iq_v, sl.d_mid, h->d_code_eo, P, ng12, nblocks, h->d_rec, sl.d_partial);
         else if (h->mfma != 1)
             hipLaunchKernelGGL(trk_stream_mfma_kernel<4>, mgrid, dim3(256), 0, h->stream, d_iq,
                                sl.d_mid, h->d_code2, P, ng12, nblocks, sl.d_partial);
@@ -897,7 +912,7 @@ int gpsmi_trk_process_dev(gpsmi_trk* h, const void* d_iq, size_t n, gpsmi_trk_ou
     }
     gpsmi_trk::Slot& sl = h->slot[0];      // the closed loop needs one slot only
     h->cur = 0;
-    rc = trk_launch(h, sl, (const float2*)d_iq, h->d_state, h->d_state, nullptr, h->max_ch,
+    rc = trk_launch(h, sl, d_iq, h->d_state, h->d_state, nullptr, h->max_ch,
                     h->max_ch);
     if (rc) return rc;
     if (out)
@@ -918,7 +933,8 @@ int gpsmi_trk_process(gpsmi_trk* h, const float* iq, size_t n, gpsmi_trk_out* ou
     GPSMI_REQUIRE(h && iq && out, "null argument");
     GPSMI_REQUIRE(n == (size_t)h->cfg.n_cyc * h->cfg.code_samples, "block must hold NGPS samples");
     GPSMI_HIP(hipSetDevice(h->cfg.device));
-    GPSMI_HIP(hipMemcpyAsync(h->d_block, iq, n * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+    GPSMI_HIP(hipMemcpyAsync(h->d_block, iq, n * (h->iq_fmt == GPSMI_IQ_U8 ? 2 : sizeof(float2)),
+                             hipMemcpyHostToDevice, h->stream));
     return gpsmi_trk_process_dev(h, h->d_block, n, out);
 }
 
@@ -970,7 +986,7 @@ int gpsmi_trk_replay_run_async(gpsmi_trk* h, const void* d_iq, int nb) {
         sl.epi_pending = false;
     }
     sl.timing_pending = h->timing;
-    return trk_launch(h, sl, (const float2*)d_iq, h->d_tab_in, h->d_tab_out,
+    return trk_launch(h, sl, d_iq, h->d_tab_in, h->d_tab_out,
                       h->replay_forced ? h->d_forced : nullptr, nb * nch, nch, /*side_epilogue=*/true);
 }
 
@@ -1060,6 +1076,16 @@ int gpsmi_trk_after_acq(gpsmi_trk* later, gpsmi_acq* earlier) {
     GPSMI_HIP(hipSetDevice(e.device));
     GPSMI_HIP(hipEventRecord(e.order, e.stream));
     GPSMI_HIP(hipStreamWaitEvent(later->stream, e.order, 0));
+    return GPSMI_OK;
+}
+
+int gpsmi_trk_set_input_format(gpsmi_trk* h, int fmt) {
+    GPSMI_REQUIRE(h, "null handle");
+    GPSMI_REQUIRE(fmt == GPSMI_IQ_C64 || fmt == GPSMI_IQ_U8, "unknown input format");
+    if (fmt == GPSMI_IQ_U8 && h->mfma != 4)
+        return fail(GPSMI_E_UNSUPPORTED, "raw u8 IQ input needs CODE_SAMPLES = 2048, N_CYC = 32 "
+                                         "(the span correlator)");
+    h->iq_fmt = fmt;
     return GPSMI_OK;
 }
 

@@ -20,9 +20,11 @@
 
 namespace gpsmi {
 
-template <int CG>
+// (FMT 1: iq holds raw uint16 (Q << 8 | I) samples, decoded on load exactly as
+// gpsmi_dev_unpack_u8iq does)
+template <int CG, int FMT = 0>
 __global__ __launch_bounds__(256) void trk_corr_kernel(
-    const float2* __restrict__ iq, const gpsmi_trk_state* __restrict__ st_in,
+    const void* __restrict__ iq, const gpsmi_trk_state* __restrict__ st_in,
     const int* __restrict__ delay_forced, const float2* __restrict__ rep,
     const float2* __restrict__ tw, TrkParams P, int ngroups, int nblocks,
     gpsmi_trk_out* __restrict__ out, JobMid* __restrict__ mid) {
@@ -41,7 +43,8 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(
     if (b >= nblocks) return;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const int cs = kFftN;
-    const float2* blk = iq + (size_t)b * ((size_t)cs * P.n_cyc);
+    const float2* blk = static_cast<const float2*>(iq) + (size_t)b * ((size_t)cs * P.n_cyc);
+    const uint16_t* rblk = static_cast<const uint16_t*>(iq) + (size_t)b * ((size_t)cs * P.n_cyc);
     const double inv_2pi = 0.15915494309189533576888376337251;
     const int first = (P.n_cyc - P.corr_avg) / 2;
     const FftTw ftw = fft_setup(lds_tw, tw, t);
@@ -89,8 +92,14 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(
         v2f x[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            const float2 v = blk[(size_t)i * cs + t + 256 * r];
-            x[r] = v2f{v.x, v.y};
+            if (FMT == 0) {
+                const float2 v = blk[(size_t)i * cs + t + 256 * r];
+                x[r] = v2f{v.x, v.y};
+            } else {
+                const unsigned v = rblk[(size_t)i * cs + t + 256 * r];
+                const float scl = 1.0f / 127.5f;
+                x[r] = v2f{sub_rn(mul_rn((float)(v & 0xFF), scl), 1.0f), sub_rn(mul_rn((float)(v >> 8), scl), 1.0f)};
+            }
         }
         v2f u[CG];
 #pragma unroll

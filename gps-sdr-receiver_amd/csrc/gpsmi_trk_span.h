@@ -167,17 +167,64 @@ __device__ __forceinline__ void sp_wave_descs(const JobMid* __restrict__ midrow,
 // 512 bytes of each.  Global address = scalar base + one lane offset (buffer loads; a tile
 // position past the block reads nothing and returns zeros).  The rows are read once:
 // non-temporal loads (3 % faster than the default policy).
-template <int AUX = 2>
-__device__ __forceinline__ void sp_load_tile(const float2* blk, int pos, int lane, sp4 (&st)[16]) {
+// FMT 1: the block is raw uint16 (Q << 8 | I) samples as the recorder writes them
+// (gpsrecv.py:168-173), 2 bytes per sample: four instructions per tile, instruction i covers
+// rows 8 i + lane / 8 and 128 bytes (64 samples) of each; sp_store_tile decodes them.
+template <int AUX = 2, int FMT = 0>
+__device__ __forceinline__ void sp_load_tile(const void* blk, int pos, int lane, sp4 (&st)[16]) {
     constexpr int CS = kFftN, NC = 32;
-    const __amdgpu_buffer_rsrc_t blk_rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float2*>(blk), 0, CS * NC * (int)sizeof(float2), kMfRsrcFlags);
-    const int ld_off = ((lane >> 5) * CS + 2 * (lane & 31)) * (int)sizeof(float2);
-    const int tb = pos * (int)sizeof(float2);
+    if (FMT == 0) {
+        const __amdgpu_buffer_rsrc_t blk_rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<void*>(blk), 0, CS * NC * (int)sizeof(float2), kMfRsrcFlags);
+        const int ld_off = ((lane >> 5) * CS + 2 * (lane & 31)) * (int)sizeof(float2);
+        const int tb = pos * (int)sizeof(float2);
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-        st[i] = __builtin_bit_cast(sp4, __builtin_amdgcn_raw_buffer_load_b128(
-            blk_rs, ld_off, tb + i * (2 * CS * (int)sizeof(float2)), AUX));
+        for (int i = 0; i < 16; ++i)
+            st[i] = __builtin_bit_cast(sp4, __builtin_amdgcn_raw_buffer_load_b128(
+                blk_rs, ld_off, tb + i * (2 * CS * (int)sizeof(float2)), AUX));
+    } else {
+        const __amdgpu_buffer_rsrc_t blk_rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<void*>(blk), 0, CS * NC * 2, kMfRsrcFlags);
+        const int ld_off = ((lane >> 3) * CS + 8 * (lane & 7)) * 2;
+        const int tb = pos * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            st[i] = __builtin_bit_cast(sp4, __builtin_amdgcn_raw_buffer_load_b128(
+                blk_rs, ld_off, tb + i * (8 * CS * 2), AUX));
+    }
+}
+// the staged tile into LDS (interleaved re / im, row pitch kSpRowDw); FMT 1 decodes the raw
+// samples exactly as gpsmi_dev_unpack_u8iq does: fl32(byte) * fl32(1 / 127.5) - 1, two roundings
+template <int FMT>
+__device__ __forceinline__ void sp_store_tile(float* tl, int lane, const sp4 (&st)[16]) {
+    if (FMT == 0) {
+        float* st_dst = tl + (lane >> 5) * kSpRowDw + 4 * (lane & 31);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {                 // rows are 8-byte aligned: two b64 writes
+            *reinterpret_cast<sp2*>(st_dst + i * 2 * kSpRowDw) = sp2{st[i].x, st[i].y};
+            *reinterpret_cast<sp2*>(st_dst + i * 2 * kSpRowDw + 2) = sp2{st[i].z, st[i].w};
+        }
+    } else {
+        float* st_dst = tl + (lane >> 3) * kSpRowDw + 16 * (lane & 7);
+        const float scl = 1.0f / 127.5f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            // (the whole vector is reinterpreted at once: with hipcc 7.2 a per-element
+            // __builtin_bit_cast(unsigned, st[i][w]) made the compiler narrow the 16-byte load
+            // to its first dword and use that for all four)
+            typedef unsigned sp_u4 __attribute__((ext_vector_type(4)));
+            const sp_u4 q = __builtin_bit_cast(sp_u4, st[i]);
+            const unsigned vv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {              // one dword = two samples
+                const unsigned v = vv[w];
+                const sp2 s0 = {(float)(v & 0xFF) * scl - 1.0f, (float)((v >> 8) & 0xFF) * scl - 1.0f};
+                const sp2 s1 = {(float)((v >> 16) & 0xFF) * scl - 1.0f, (float)(v >> 24) * scl - 1.0f};
+                *reinterpret_cast<sp2*>(st_dst + i * 8 * kSpRowDw + 4 * w) = s0;
+                *reinterpret_cast<sp2*>(st_dst + i * 8 * kSpRowDw + 4 * w + 2) = s1;
+            }
+        }
+    }
 }
 
 // One wave: NSPANS consecutive spans starting at position `pos0` (a multiple of 64) of a
@@ -187,8 +234,8 @@ __device__ __forceinline__ void sp_load_tile(const float2* blk, int pos, int lan
 // sums of the range for [M tile][N tile] in (tot, lo_fin): lo_fin = what was summed below the
 // delay when the boundary lies inside the range, tot = the rest.
 // (DIAG, probes only: 1 no MFMAs, 2 no row loads after the first tile, 8 default cache policy)
-template <int NSPANS, int DIAG = 0>
-__device__ __forceinline__ void span_wave(const float2* __restrict__ blk, const float2* next_blk,
+template <int NSPANS, int DIAG = 0, int FMT = 0>
+__device__ __forceinline__ void span_wave(const void* __restrict__ blk, const void* next_blk,
                                           int next_pos, float* tl, float* cd, const SpDesc (&mdd)[2],
                                           const SpDesc& smd, const float* __restrict__ code_eo,
                                           int pos0, int lane, sp4 (&st)[16], sp4 (&tot)[2][2],
@@ -197,14 +244,7 @@ __device__ __forceinline__ void span_wave(const float2* __restrict__ blk, const 
     const int j = lane & 15, k = lane >> 4, pi = k >> 1, kap = k & 1, part = j & 1;
     const int q0 = pos0 & ~(kSpQuarter - 1);                      // start of the quarter
     constexpr int kTiles = NSPANS;
-    float* st_dst = tl + (lane >> 5) * kSpRowDw + 4 * (lane & 31);
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {                 // rows are 8-byte aligned: two b64 writes
-            *reinterpret_cast<sp2*>(st_dst + i * 2 * kSpRowDw) = sp2{st[i].x, st[i].y};
-            *reinterpret_cast<sp2*>(st_dst + i * 2 * kSpRowDw + 2) = sp2{st[i].z, st[i].w};
-        }
-    };
+    auto store_tile = [&]() { sp_store_tile<FMT>(tl, lane, st); };
 
     // ---- lane roles: two channels (one per N tile); the recurrence of both, seeded with the
     // exact phasor of the lane's first two positions of the QUARTER
@@ -314,8 +354,8 @@ __device__ __forceinline__ void span_wave(const float2* __restrict__ blk, const 
         load_code(2 * tix + 1);
         if (!(DIAG & 2)) {
             const bool more = tix + 1 < kTiles;            // else: the first tile of the wave's next range
-            sp_load_tile<(DIAG & 8) ? 0 : 2>(more ? blk : next_blk, more ? pos0 + (tix + 1) * kSpTile : next_pos,
-                                             lane, st);
+            sp_load_tile<(DIAG & 8) ? 0 : 2, FMT>(more ? blk : next_blk,
+                                                  more ? pos0 + (tix + 1) * kSpTile : next_pos, lane, st);
         }
         __builtin_amdgcn_sched_barrier(0);
         const int tpos = rel0 + tix * kSpTile;                       // tile start within the quarter
@@ -454,9 +494,10 @@ __device__ __forceinline__ void span_wave(const float2* __restrict__ blk, const 
 constexpr int kSpRecFloats = 2 * 16 * 64;              // one wave's record
 constexpr int kSpLoOfs = 16 * 64;                      // lo_fin within it
 
-template <int NSPANS, int WAVES, int DIAG = 0>
+// (FMT 1: iq holds raw uint16 samples, 2 bytes each, decoded on the way into LDS)
+template <int NSPANS, int WAVES, int DIAG = 0, int FMT = 0>
 __global__ __launch_bounds__(64 * WAVES, 2) void trk_span_kernel(
-    const float2* __restrict__ iq, const JobMid* __restrict__ mid,
+    const void* __restrict__ iq_v, const JobMid* __restrict__ mid,
     const float* __restrict__ code_eo, TrkParams P, int ngroups, int nblocks,
     float* __restrict__ rec, float2* __restrict__ partial) {
     constexpr int NC = 32, CS = kFftN;
@@ -464,6 +505,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void trk_span_kernel(
     constexpr bool kWholeBlock = kRanges == WAVES;      // the workgroup holds all ranges of its block
     static_assert(kRanges % WAVES == 0, "the waves of a workgroup share a block");
     constexpr int kNowhere = CS * NC;                   // a tile position past the block: reads nothing
+    constexpr size_t kBlkBytes = (size_t)CS * NC * (FMT == 0 ? sizeof(float2) : 2);
+    const char* iq = static_cast<const char*>(iq_v);
     __shared__ __attribute__((aligned(16))) float lds[WAVES][kSpWaveFloats];
     __shared__ float4 ufac[kWholeBlock ? kSpCh * (NC + 1) : 1];      // (U[q], U[q+1]); .w = NaN: channel closed
     const int lane = threadIdx.x & 63;
@@ -481,12 +524,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void trk_span_kernel(
         const int unit = widx / kRanges, range = widx % kRanges;
         if (unit >= nunits) return;
         const int g = unit % ngroups, b = unit / ngroups;
-        const float2* blk = iq + (size_t)b * ((size_t)CS * NC);
+        const char* blk = iq + (size_t)b * kBlkBytes;
         const int pos0 = range * NSPANS * kSpTile;
-        sp_load_tile<(DIAG & 8) ? 0 : 2>(blk, pos0, lane, st);   // before anything that depends on the descriptors
+        sp_load_tile<(DIAG & 8) ? 0 : 2, FMT>(blk, pos0, lane, st);   // before anything that depends on the descriptors
         sp_wave_descs(mid + (size_t)b * P.nch + g * kSpCh, P.nch - g * kSpCh, lane, md, smd);
-        span_wave<NSPANS, DIAG>(blk, blk, kNowhere, tl, tl + kSpTileFloats, md, smd, code_eo, pos0, lane, st, tot,
-                                lo_fin, all_lo, pb);
+        span_wave<NSPANS, DIAG, FMT>(blk, blk, kNowhere, tl, tl + kSpTileFloats, md, smd, code_eo, pos0, lane, st,
+                                     tot, lo_fin, all_lo, pb);
         float* o = rec + ((size_t)unit * kRanges + range) * kSpRecFloats + lane;
         const int rel0 = pos0 & (kSpQuarter - 1);
 #pragma unroll
@@ -542,7 +585,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void trk_span_kernel(
     };
     {
         const int g = unit % ngroups, b = unit / ngroups;
-        sp_load_tile<(DIAG & 8) ? 0 : 2>(iq + (size_t)b * ((size_t)CS * NC), pos0, lane, st);
+        sp_load_tile<(DIAG & 8) ? 0 : 2, FMT>(iq + (size_t)b * kBlkBytes, pos0, lane, st);
         sp_wave_descs(mid + (size_t)b * P.nch + g * kSpCh, P.nch - g * kSpCh, lane, md, smd);
         fetch_items(unit);
     }
@@ -554,11 +597,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void trk_span_kernel(
         // being carried through the tile loop in registers the loop needs)
         int lane_u = lane;
         asm volatile("" : "+v"(lane_u));
-        const float2* blk = iq + (size_t)b * ((size_t)CS * NC);
+        const char* blk = iq + (size_t)b * kBlkBytes;
         const int next = unit + (int)gridDim.x;
         const bool has_next = next < nunits;
-        const float2* next_blk = has_next ? iq + (size_t)(next / ngroups) * ((size_t)CS * NC) : blk;
-        span_wave<NSPANS, DIAG>(blk, next_blk, has_next ? pos0 : kNowhere, tl, tl + kSpTileFloats, md, smd, code_eo,
+        const char* next_blk = has_next ? iq + (size_t)(next / ngroups) * kBlkBytes : blk;
+        span_wave<NSPANS, DIAG, FMT>(blk, next_blk, has_next ? pos0 : kNowhere, tl, tl + kSpTileFloats, md, smd, code_eo,
                                 pos0, lane_u, st, tot, lo_fin, all_lo, pb);
         // the hi / lo sums of every row of the quarter into LDS (the wave's own tile area),
         // D[i = 4 (lane / 16) + v][j = lane % 16]

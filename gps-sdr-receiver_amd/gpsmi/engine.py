@@ -271,7 +271,8 @@ class TrkEngine:
                                                  ptr(out)),
                   'gpsmi_trk_process_dev')
         else:
-            iq = np.ascontiguousarray(iq, dtype=np.complex64)
+            iq = np.ascontiguousarray(iq, dtype=np.uint16 if getattr(self, 'raw_u8', False)
+                                      else np.complex64)
             if out is None:
                 out = np.zeros(self.max_ch, dtype=OUT_DTYPE)
             check(self.lib.gpsmi_trk_process(self.h, ptr(iq), iq.size, ptr(out)),
@@ -323,6 +324,13 @@ class TrkEngine:
     def after(self, acq_engine):
         """Later work of this handle starts when the AcqEngine's enqueued work is done."""
         check(self.lib.gpsmi_trk_after_acq(self.h, acq_engine.h), 'gpsmi_trk_after_acq')
+
+    def set_input_format(self, raw_u8):
+        """raw_u8 = True: the blocks handed to process / replay are the recorder's uint16
+        (Q << 8 | I) samples (gpsrecv.py:162-173), decoded inside the kernels that read IQ."""
+        check(self.lib.gpsmi_trk_set_input_format(self.h, 1 if raw_u8 else 0),
+              'gpsmi_trk_set_input_format')
+        self.raw_u8 = bool(raw_u8)
 
     def set_timing(self, on):
         """Kernel-timing events for the launches that follow (see gpsmi.h)."""

@@ -219,6 +219,16 @@ int gpsmi_trk_process(gpsmi_trk* h, const float* iq, size_t n,
 int gpsmi_trk_process_dev(gpsmi_trk* h, const void* d_iq, size_t n,
                           gpsmi_trk_out* out);
 
+/* Input format of the blocks that process / process_dev / replay* receive (default
+ * GPSMI_IQ_C64).  GPSMI_IQ_U8: the raw recording format of streamData (gpsrecv.py:162-173),
+ * uint16 (Q << 8 | I) per sample, 2 bytes instead of 8 over PCIe and from HBM; the kernels
+ * that read IQ decode on load, bit for bit what gpsmi_dev_unpack_u8iq writes, so every
+ * output equals the complex64 path's.  CODE_SAMPLES = 2048 and N_CYC = 32 only
+ * (GPSMI_E_UNSUPPORTED otherwise); block sizes are still counted in samples.           */
+#define GPSMI_IQ_C64 0
+#define GPSMI_IQ_U8  1
+int gpsmi_trk_set_input_format(gpsmi_trk* h, int fmt);
+
 /* Replay (open loop): nb blocks resident in device memory, the state at the
  * START of every block supplied as a table [nb][nch] (one row per block, one
  * column per open channel in channel order), all blocks processed in one batch.

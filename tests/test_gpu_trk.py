@@ -155,6 +155,37 @@ def test_replay_without_forced_delay(closed_loop):
     assert rep.tobytes() == outs[:nb].tobytes()
 
 
+def test_raw_u8_input_equals_complex64_input(closed_loop, golden_default):
+    """Fused ingest (gpsrecv.py:162-173): the kernels that read IQ decode the recorder's
+    uint16 (Q << 8 | I) samples themselves.  Closed loop (host blocks, single-block kernels)
+    and replay (batch kernels) on the raw blocks must equal the complex64 path byte for byte."""
+    from conftest import scene_for
+    from gpsmi.engine import TrkEngine, DeviceBuffer
+    _, outs, states, _ = closed_loop
+    nb, nch = outs.shape
+    sc = scene_for('default')
+    raw = [sc.block_raw(5 + i) for i in range(nb)]
+    eng = TrkEngine(max_ch=nch)
+    eng.set_input_format(True)
+    _open_all(eng, golden_default)
+    n_cl = 6
+    got = np.array([eng.process(raw[i]) for i in range(n_cl)])
+    assert got.tobytes() == outs[:n_cl].tobytes()
+    buf = DeviceBuffer(nb * raw[0].nbytes)
+    for i, b in enumerate(raw):
+        buf.upload(b, i * b.nbytes)
+    rep = eng.replay(buf.ptr, nb, states, outs['delay_used'])
+    buf.free()
+    eng.close()
+    assert rep.tobytes() == outs.tobytes()
+    # other block / code lengths have no fused path: refused, not silently converted
+    from gpsmi.engine import Config, EngineError
+    e2 = TrkEngine(Config(code_samples=16368, n_cyc=8), max_ch=2)
+    with pytest.raises(EngineError):
+        e2.set_input_format(True)
+    e2.close()
+
+
 def test_block_from_device_memory(golden_default):
     """process() on a device-resident block equals process() on a host block."""
     from gpsmi.engine import TrkEngine, DeviceBuffer
