@@ -182,6 +182,36 @@ def measure_cfg4(E, acq, d_iq, reps=10):
             'bound': 'LDS / VALU (FFT); algorithmic HBM bytes 0.75 MB per search'}
 
 
+def measure_u8(E, local, d_raw, nb, chans, states, delay_used, expect, iters=8):
+    """the same replay with the raw uint16 recording as input (2 bytes per
+    sample from HBM, decoded inside the kernels that read IQ) -- its own roofline regime."""
+    trk = E.TrkEngine(E.Config(device=local), max_ch=max(1, len(chans)))
+    trk.set_input_format(True)
+    for c, (s, f, d) in enumerate(chans):
+        trk.open(c, s, f, d)
+    trk.replay_load(nb, states, delay_used)
+    base = d_raw.at(N_ACQ_BLOCKS * NGPS * 2)
+    tot, cor = [], []
+    for i in range(iters + 2):
+        trk.replay_run(base, nb)
+        if i >= 2:
+            t, c = trk.last_ms()
+            tot.append(t)
+            cor.append(c)
+    out = np.zeros_like(expect)
+    trk.replay_fetch(out)
+    trk.close()
+    c, t = float(np.median(cor)), float(np.median(tot))
+    gb = nb * NGPS * 2 / 1e9
+    return {'config': f'fused ingest: the configs[2] replay on raw uint16 (Q<<8|I) IQ, {nb} blocks = '
+                      f'{nb * NGPS * 2 / 2**20:.0f} MiB resident, 2 B per sample',
+            'correlator_ms': round(c, 4), 'correlator_gbs': round(gb / c * 1e3, 1),
+            'correlator_frac_of_hbm_peak': round(gb / c * 1e3 / HBM_PEAK_GBS, 4),
+            'bound': 'MFMA / VALU issue (the decode adds 6 VALU operations per sample), not HBM',
+            'tracking_all_ms': round(t, 4), 'msamples_per_s': round(nb * NGPS / t / 1e3, 1),
+            'equals_complex64_path': bool(out.tobytes() == expect.tobytes())}
+
+
 def measure_cfg5(E, local, iters=8):
     """configs[4]: 12-channel tracking at 16.368 Msps, N_CYC = 8 (block = 130944 samples),
     512 blocks = 512 MiB resident, replay from a synthetic state table (random IQ: a
@@ -288,8 +318,7 @@ def main():
     d_raw.upload(raw)
     d_iq = E.DeviceBuffer(raw.size * 8, local)
     E.unpack_u8iq(d_iq.ptr, d_raw.ptr, raw.size, local)   # streamData's decode
-    d_raw.free()
-    blk_bytes = NGPS * 8
+    blk_bytes = NGPS * 8                                  # (d_raw stays: the fused-ingest leg reads it)
     d_iq0 = d_iq                                          # block 0 of the common stream
     if first != 0:
         d_raw0 = E.DeviceBuffer(raw0.nbytes, local)
@@ -496,6 +525,7 @@ def main():
     if rank == 0 and not a.no_extra:
         extra.append(measure_cfg4(E, acq, d_iq0.ptr))
         if world == 1:
+            extra.append(measure_u8(E, local, d_raw, nb, chans, states, cl_out['delay_used'], cl_out))
             extra.append(measure_cfg5(E, local))
 
     if rank == 0:

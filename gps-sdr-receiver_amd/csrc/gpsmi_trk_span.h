@@ -332,12 +332,17 @@ __device__ __forceinline__ void span_wave(const void* __restrict__ blk, const vo
             acc[mt][n] = zero4;
         }
     };
+    // the boundaries of the group's channels as scalars (channel c sits in lane 2 (c % 8) of N
+    // tile c / 8): the next one is a dozen scalar compares, no cross-lane reduction in the loop
+    int pbs[kSpCh];
+#pragma unroll
+    for (int c = 0; c < kSpCh; ++c) pbs[c] = __builtin_amdgcn_readlane(pb[c >> 3], 2 * (c & 7));
     auto next_boundary = [&](int after) {                            // first boundary position > after
         int v = kSpInf;
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
-            if (pb[n] > after && pb[n] < rel0 + NSPANS * kSpTile) v = pb[n] < v ? pb[n] : v;
-        return sp_wave_min(v);
+        for (int c = 0; c < kSpCh; ++c)
+            if (pbs[c] > after && pbs[c] < rel0 + NSPANS * kSpTile) v = pbs[c] < v ? pbs[c] : v;
+        return v;
     };
     int nb = next_boundary(rel0);        // (a boundary AT the range start needs no action: all hi)
     const float* ap0 = tl + (lane & 15) * kSpRowDw + k;              // lane = (row, k), rows 0 .. 15
