@@ -16,6 +16,7 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY 
   timeout -k 10 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/pmc/pass$i -- python3 tools/kernel_bench.py --iters 3 > $out/pmc_pass$i.log 2>&1 || { echo "pmc pass $i failed"; tail -5 $out/pmc_pass$i.log; }
 done
 python3 tools/pmc_summary.py $out/pmc > $out/replay_pmc_counters.txt
+tools/probe/span_prof 1024 > $out/span_prof.txt 2>&1 || echo "span_prof failed"
 python3 tools/kernel_bench.py > $out/kernel_bench.txt 2>&1
 python3 tools/kernel_bench.py --delays aligned >> $out/kernel_bench.txt 2>&1
 python3 tools/kernel_bench.py --code-samples 16368 --n-cyc 8 --blocks 512 --iters 5 >> $out/kernel_bench.txt 2>&1
