@@ -662,6 +662,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void trk_span_kernel(
                     sp_window(hx, hy, lx, ly, make_float2(uf.x, uf.y), make_float2(uf.z, uf.w));
             }
         }
+        if (DIAG & 4) {                                  // (probe: keep the sums alive without the combine step)
+            if (tot[0][0][0] + tot[0][1][1] + tot[1][0][2] + tot[1][1][3] + lo_fin[0][0][0] + lo_fin[1][1][1] == 123.456f)
+                partial[(size_t)unit * 64 + lane] = make_float2(tot[0][0][0], lo_fin[1][1][1]);
+        }
         if (!has_next) break;
         if (!(DIAG & 4)) __syncthreads();               // the tile areas are free again
         unit = next;
