@@ -260,8 +260,8 @@ def main():
     os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--blocks', type=int, default=1024)
     ap.add_argument('--cpu-blocks', type=int, default=192)
     ap.add_argument('--no-cpu', action='store_true')

@@ -55,8 +55,8 @@ struct TrkParams {
     int df_no;         // 1024 / n_cyc
     float t_last;      // SEC_TIME[NGPS-1]
     float om_min, om_max;   // float32(2*pi*MIN_FREQ), float32(2*pi*MAX_FREQ) from float64
-    int flags;              // diagnostics only (GPSMI_DEBUG_FLAGS): 1 no MAC, 2 no lane sums, 4 no mixed fix,
-                            // 8 LDS-ring correlator, 16 the timed span correlator launch is a repeat
+    int flags;              // diagnostics only (GPSMI_DEBUG_FLAGS): 1 no MAC, 2 no lane sums, 4 no mixed fix
+                            // (vector correlator), 16 the timed span correlator launch is a repeat
 };
 
 // per-job descriptor handed from the correlation kernel to the correlator and
@@ -109,7 +109,6 @@ __device__ inline double fit_code_phase(double lo, double pk, double hi, int mx)
 
 #pragma clang fp contract(fast)
 #include "gpsmi_trk_stream.h"
-#include "gpsmi_trk_stream_lds.h"
 #include "gpsmi_trk_stream_mfma.h"
 #include "gpsmi_trk_corr.h"
 #include "gpsmi_bigfft.h"
@@ -536,7 +535,7 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
         else
             hipLaunchKernelGGL(trk_stream_mfma_kernel<8>, mgrid, dim3(512), 0, h->stream, d_iq,
                                sl.d_mid, h->d_code2, P, ng12, nblocks, sl.d_partial);
-    } else if (!(P.flags & 8) || h->general) {    // default: the register-staged correlator
+    } else {                               // the vector correlator (other block / code lengths)
         const dim3 grid(sgrid.x, h->nchunks), block(kStreamThreads);
         float2* pdst = h->nchunks > 1 ? h->d_partial_g : sl.d_partial;
 #define GPSMI_LAUNCH_STREAM(NC, POW2, J)                                                        \
@@ -563,23 +562,6 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
                                dim3(256), 0, h->stream, h->d_partial_g, h->nchunks, per_job, njobs,
                                sl.d_mid, sl.d_partial);
         }
-    } else {                               // GPSMI_DEBUG_FLAGS=8: the LDS-ring variant
-#define GPSMI_LAUNCH_LDS(NC, G)                                                                 \
-    hipLaunchKernelGGL((trk_stream_lds_kernel<NC, G>), dim3(nblocks* nsuper), dim3(256 * G), 0, \
-                       h->stream, d_iq, st_in, sl.d_mid, h->d_code, P, nsuper, nblocks,          \
-                       sl.d_partial)
-        const int G = nch > kGroupCh ? 2 : 1;
-        const int nsuper = (nch + kGroupCh * G - 1) / (kGroupCh * G);
-        if (G == 2) {
-            if (P.n_cyc == 32) GPSMI_LAUNCH_LDS(32, 2);
-            else if (P.n_cyc == 16) GPSMI_LAUNCH_LDS(16, 2);
-            else GPSMI_LAUNCH_LDS(8, 2);
-        } else {
-            if (P.n_cyc == 32) GPSMI_LAUNCH_LDS(32, 1);
-            else if (P.n_cyc == 16) GPSMI_LAUNCH_LDS(16, 1);
-            else GPSMI_LAUNCH_LDS(8, 1);
-        }
-#undef GPSMI_LAUNCH_LDS
     }
     if (timed && !ext_timed) GPSMI_HIP(hipEventRecord(sl.ev[2], h->stream));
     // replay: the epilogue goes to a stream of its own behind the correlator, so that the

@@ -266,17 +266,15 @@ def test_channel_management_and_errors():
     eng.close()
 
 
-def test_lds_ring_correlator_variant_agrees(closed_loop, monkeypatch):
-    """The LDS-ring form of the correlator (GPSMI_DEBUG_FLAGS=8, kept for A/B
-    work) computes the same windows as the default register-staged kernel; only
-    the summation order over lanes differs."""
+def test_round1_matrix_correlator_agrees(closed_loop, monkeypatch):
+    """GPSMI_STREAM_MFMA=3: the round-1 correlator (v_mfma_f32_32x32x2_f32, four waves x 512
+    positions per workgroup, gpsmi_trk_stream_mfma.h) computes the same windows as the span
+    correlator; only the order of the float32 sums differs."""
     from gpsmi.engine import TrkEngine, DeviceBuffer
     _, outs, states, blocks = closed_loop
     nb, nch = 8, outs.shape[1]
-    monkeypatch.setenv('GPSMI_DEBUG_FLAGS', '8')
-    monkeypatch.setenv('GPSMI_STREAM_MFMA', '0')
+    monkeypatch.setenv('GPSMI_STREAM_MFMA', '3')
     eng = TrkEngine(max_ch=nch)
-    monkeypatch.delenv('GPSMI_DEBUG_FLAGS')
     monkeypatch.delenv('GPSMI_STREAM_MFMA')
     buf = DeviceBuffer(nb * blocks[0].nbytes)
     for i in range(nb):
