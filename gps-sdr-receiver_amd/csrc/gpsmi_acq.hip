@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void acq_corr_kernel(
     fft2048(v, lds, ftw, t);
     float mag[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) mag[q] = sqrtf(v[q].x * v[q].x + v[q].y * v[q].y) * (1.0f / kFftN);
+    for (int q = 0; q < 8; ++q) mag[q] = __builtin_amdgcn_sqrtf(v[q].x * v[q].x + v[q].y * v[q].y) * (1.0f / kFftN);   // v_sqrt_f32, 1 ulp
     int amax; float peak, mean, sd, lo, hi;
     corr_stats8(mag, t, magbuf, red, amax, peak, mean, sd, lo, hi);
     if (t == 0) {

@@ -109,7 +109,7 @@ struct FftTw {
 __device__ __forceinline__ FftTw fft_setup(float* lds_tw, const float2* __restrict__ tw, int t) {
     float2* t64 = reinterpret_cast<float2*>(lds_tw);
     float2* t512 = t64 + 64;
-    if (t < 64) t64[t] = tw[32 * t];
+    t64[t & 63] = tw[32 * (t & 63)];                // (every wave writes the same 64 entries: no branch to wait in)
     t512[t] = tw[4 * t];
     t512[t + 256] = tw[4 * (t + 256)];
     FftTw f;

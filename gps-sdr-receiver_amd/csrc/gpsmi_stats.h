@@ -26,22 +26,34 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 }
 
 template <int CTRL, int ROWS>
-__device__ __forceinline__ void dpp_argmax_step(float& v, int& i) {
+__device__ __forceinline__ float dpp_max_own(float v) {   // max(v, partner), v where no partner
     const int vi = __builtin_bit_cast(int, v);
-    const float ov = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(vi, vi, CTRL, ROWS, 0xF, false));
-    const int oi = __builtin_amdgcn_update_dpp(i, i, CTRL, ROWS, 0xF, false);
-    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    return fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(vi, vi, CTRL, ROWS, 0xF, false)));
 }
-// maximum and its smallest index over the 64 lanes, broadcast to all of them
+template <int CTRL, int ROWS>
+__device__ __forceinline__ int dpp_min_own(int v) {
+    return min(v, __builtin_amdgcn_update_dpp(v, v, CTRL, ROWS, 0xF, false));
+}
+// maximum and its smallest index over the 64 lanes, broadcast to all of them: the maximum
+// first, then the smallest index among the lanes that hold it (12 DPP steps, no branches)
 __device__ __forceinline__ void wave_argmax_dpp(float& v, int& i) {
-    dpp_argmax_step<0xB1, 0xF>(v, i);
-    dpp_argmax_step<0x4E, 0xF>(v, i);
-    dpp_argmax_step<0x141, 0xF>(v, i);
-    dpp_argmax_step<0x140, 0xF>(v, i);
-    dpp_argmax_step<0x142, 0xA>(v, i);
-    dpp_argmax_step<0x143, 0xC>(v, i);
-    v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-    i = __builtin_amdgcn_readlane(i, 63);
+    float m = v;
+    m = dpp_max_own<0xB1, 0xF>(m);
+    m = dpp_max_own<0x4E, 0xF>(m);
+    m = dpp_max_own<0x141, 0xF>(m);
+    m = dpp_max_own<0x140, 0xF>(m);
+    m = dpp_max_own<0x142, 0xA>(m);
+    m = dpp_max_own<0x143, 0xC>(m);
+    m = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 63));
+    int k = v == m ? i : 0x7fffffff;
+    k = dpp_min_own<0xB1, 0xF>(k);
+    k = dpp_min_own<0x4E, 0xF>(k);
+    k = dpp_min_own<0x141, 0xF>(k);
+    k = dpp_min_own<0x140, 0xF>(k);
+    k = dpp_min_own<0x142, 0xA>(k);
+    k = dpp_min_own<0x143, 0xC>(k);
+    v = m;
+    i = __builtin_amdgcn_readlane(k, 63);
 }
 
 constexpr int kStatsRedFloats = 16;

@@ -15,15 +15,52 @@
 // thread 0 applies the CORR_MIN threshold, the peak fit and chooses the DELAY
 // the block is decoded with (gpslib.py:1181-1182).
 #pragma once
+#include <type_traits>
 #include "gpsmi_fft.h"
 #include "gpsmi_stats.h"
 
 namespace gpsmi {
 
+// One channel's correlation result -> its output record and the correlator's job entry.
+constexpr int kFoldDepth = 3;      // rows of the fold in flight per workgroup
+constexpr int kFoldChunk = 8;      // the row count the pipelined fold is written for (CORR_AVG of the reference)
+
+struct CorrFin { int bi; float bv, mean, sd, elo, ehi; };
+
+__device__ __forceinline__ void corr_finish(const StreamChan& s, const CorrFin& f, const TrkParams& P,
+                                            const int* __restrict__ delay_forced,
+                                            gpsmi_trk_out* __restrict__ out, JobMid* __restrict__ mid) {
+    const int bi = f.bi;
+    const float bv = f.bv, mean = f.mean, sd = f.sd, elo = f.elo, ehi = f.ehi;
+    const float norm = (bv - mean) / sd;
+    gpsmi_trk_out& o = out[s.job];
+    o.prn = s.prn;
+    o.mx = bi;
+    o.epl[0] = elo; o.epl[1] = bv; o.epl[2] = ehi;
+    o.corr_mean = mean; o.corr_std = sd;
+    o.norm_max_corr = norm;
+    int delay = -1;
+    double cp = -1.0;
+    if (norm > P.corr_min) {
+        delay = bi;
+        cp = fit_code_phase((double)elo, (double)bv, (double)ehi, bi);
+    }
+    o.delay = delay;
+    o.reserved0 = 0;
+    o.code_phase = cp;
+    int used = delay >= 0 ? delay : s.d;
+    if (delay_forced && delay_forced[s.job] >= 0) used = delay_forced[s.job];
+    o.delay_used = used;
+    JobMid md;
+    md.delay_used = used; md.active = 1; md.prn = s.prn; md.om = s.om; md.ph = s.ph;
+    md.pad[0] = md.pad[1] = md.pad[2] = 0;
+    mid[s.job] = md;
+}
+
 // (FMT 1: iq holds raw uint16 (Q << 8 | I) samples, decoded on load exactly as
 // gpsmi_dev_unpack_u8iq does)
 template <int CG, int FMT = 0>
-__global__ __launch_bounds__(256) void trk_corr_kernel(
+__global__ __launch_bounds__(256, CG > 4 ? 2 : 3) void trk_corr_kernel(
     const void* __restrict__ iq, const gpsmi_trk_state* __restrict__ st_in,
     const int* __restrict__ delay_forced, const float2* __restrict__ rep,
     const float2* __restrict__ tw, TrkParams P, int ngroups, int nblocks,
@@ -43,19 +80,60 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(
     static_assert(kFftN <= 2 * kFftPlane1 && CG * 32 * 2 <= 2 * kFftPlane1, "aliases must fit buffer 1");
     __shared__ float2 step[CG];                  // exp(-j w 256/fs)
     __shared__ StreamChan schan[CG];
+    __shared__ CorrFin fin[CG];
+    __shared__ float2 vtab[CG][32];              // the factors of V(t), see the prologue
 
     const int wg = blockIdx.x;
     const int xcd = wg & 7, slot = wg >> 3;
     const int g = slot % ngroups;
     const int b = (slot / ngroups) * 8 + xcd;
     if (b >= nblocks) return;
-    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int t = threadIdx.x;
     const int cs = kFftN;
     const float2* blk = static_cast<const float2*>(iq) + (size_t)b * ((size_t)cs * P.n_cyc);
     const uint16_t* rblk = static_cast<const uint16_t*>(iq) + (size_t)b * ((size_t)cs * P.n_cyc);
     const double inv_2pi = 0.15915494309189533576888376337251;
     const int first = (P.n_cyc - P.corr_avg) / 2;
+    // The rows of the fold stream through kFoldDepth x 8 registers per thread: the first rows are
+    // requested here, ahead of the per-channel constants, and as soon as a position of row i has
+    // gone into the accumulators its register is reloaded with the same position of row
+    // i + kFoldDepth: that many rows stay in flight instead of one round trip to memory per row
+    // (the registers are free: the transforms that follow need more than the fold does).
+    // The channel state of the threads that set up the per-channel constants below: every field
+    // is requested here, with the first rows and the twiddles, so that the prologue makes one
+    // trip to memory instead of one per dependent load.
+    const int pc_c = min(t / 33, CG - 1);
+    const gpsmi_trk_state& st = st_in[b * P.nch + min(g * CG + pc_c, P.nch - 1)];
+    int st_prn = st.prn, st_delay = st.delay;
+    float st_om0 = st.omega0, st_freq = st.freq, st_phase = st.phase;
+    using Raw = typename std::conditional<FMT == 0, v2f, unsigned>::type;
+    auto fetch = [&](int i, int r) -> Raw {
+        if constexpr (FMT == 0) {
+            const float2 v = blk[(size_t)i * cs + t + 256 * r];
+            return v2f{v.x, v.y};
+        } else {
+            return (unsigned)rblk[(size_t)i * cs + t + 256 * r];
+        }
+    };
+    auto decode = [&](Raw v) -> v2f {
+        if constexpr (FMT == 0) {
+            return v;
+        } else {
+            const float scl = 1.0f / 127.5f;
+            return v2f{sub_rn(mul_rn((float)(v & 0xFF), scl), 1.0f), sub_rn(mul_rn((float)(v >> 8), scl), 1.0f)};
+        }
+    };
+    Raw x[kFoldDepth][8];
+    const bool nofold = P.flags & 32;                     // diagnostics: no fold at all
+    const bool piped = P.corr_avg == kFoldChunk && !nofold;   // any other row count: one row at a time
+    if (piped) {
+#pragma unroll
+        for (int k = 0; k < kFoldDepth; ++k)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) x[k][r] = fetch(first + k, r);
+    }
     const FftTw ftw = fft_setup(lds_tw, tw, t);
+    asm volatile("" : "+v"(st_prn), "+v"(st_delay), "+v"(st_om0), "+v"(st_freq), "+v"(st_phase));   // (pins the loads above this line)
 
     // ---- per-channel constants (one thread each), then one barrier
     if (t < CG * 33) {
@@ -64,18 +142,23 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(
         const int job = b * P.nch + cidx;
         StreamChan s;
         s.job = job; s.active = 0; s.om = 0.f; s.ph = 0.f; s.d = 0; s.prn = 0;
-        if (cidx < P.nch && st_in[job].prn > 0) {
-            const gpsmi_trk_state& st = st_in[job];
+        if (cidx < P.nch && st_prn > 0) {
             s.active = 1;
-            s.om = st.omega0 != 0.f ? st.omega0 : omega_of(st.freq);
-            s.ph = st.phase;
-            s.d = st.delay;
-            s.prn = st.prn;
+            s.om = st_om0 != 0.f ? st_om0 : omega_of(st_freq);
+            s.ph = st_phase;
+            s.d = st_delay;
+            s.prn = st_prn;
         }
         const double f_eff = (double)s.om * inv_2pi;
         if (i < 32) {
             const double rev = f_eff * (double)i * 1.0e-3;            // w i T / 2 pi
             urow[c][i] = phasor_rev((float)(rev - rint(rev)));
+            // V at position t = 16 h + k is vtab[k] * vtab[16 + h]: the phase of the channel and
+            // position k + 1 in the first factor, 16 h positions in the second
+            const double per = f_eff / (1000.0 * (double)cs);         // revolutions per position
+            const double rv = i < 16 ? per * (double)(i + 1) + (double)s.ph * inv_2pi
+                                     : per * (double)(16 * (i - 16));
+            vtab[c][i] = phasor_rev((float)(rv - rint(rv)));
         } else {
             const double rev = f_eff * 256.0 / (1000.0 * (double)cs);
             step[c] = phasor_rev((float)(rev - rint(rev)));
@@ -96,102 +179,110 @@ __global__ __launch_bounds__(256) void trk_corr_kernel(
     for (int c = 0; c < CG; ++c)
 #pragma unroll
         for (int r = 0; r < 8; ++r) acc[c][r] = v2f{0.f, 0.f};
-    for (int i = first; i < first + P.corr_avg; ++i) {
-        v2f x[8];
+    auto fold_in = [&](const v2f (&u)[CG], int r, v2f xr, v2f xprev) {
+        if constexpr (CG == 1) {                 // (cmac2 works on pairs: two positions at once)
+            if (r & 1) cmac2(acc[0][r - 1], acc[0][r], u[0], xprev, u[0], xr);
+        } else {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            if (FMT == 0) {
-                const float2 v = blk[(size_t)i * cs + t + 256 * r];
-                x[r] = v2f{v.x, v.y};
-            } else {
-                const unsigned v = rblk[(size_t)i * cs + t + 256 * r];
-                const float scl = 1.0f / 127.5f;
-                x[r] = v2f{sub_rn(mul_rn((float)(v & 0xFF), scl), 1.0f), sub_rn(mul_rn((float)(v >> 8), scl), 1.0f)};
-            }
+            for (int c = 0; c + 1 < CG; c += 2)
+                cmac2(acc[c][r], acc[c + 1][r], u[c], xr, u[c + 1], xr);
         }
+    };
+    auto fold_row = [&](int i, Raw (&xk)[8], auto reload, int inext) {
         v2f u[CG];
 #pragma unroll
         for (int c = 0; c < CG; ++c) u[c] = v2f{urow[c][i].x, urow[c][i].y};
+        v2f xprev = v2f{0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            if (CG == 1) {                       // (cmac2 works on pairs: two positions at once)
-                if (r & 1) cmac2(acc[0][r - 1], acc[0][r], u[0], x[r - 1], u[0], x[r]);
-            } else {
+            const v2f xr = decode(xk[r]);
+            if constexpr (decltype(reload)::value) xk[r] = fetch(inext, r);
+            fold_in(u, r, xr, xprev);
+            xprev = xr;
+        }
+    };
+    if (piped) {
 #pragma unroll
-                for (int c = 0; c + 1 < CG; c += 2)
-                    cmac2(acc[c][r], acc[c + 1][r], u[c], x[r], u[c + 1], x[r]);
-            }
+        for (int j = 0; j < kFoldChunk; ++j) {            // straight-line code: exact wait counts
+            if (j + kFoldDepth < kFoldChunk)
+                fold_row(first + j, x[j % kFoldDepth], std::true_type{}, first + j + kFoldDepth);
+            else
+                fold_row(first + j, x[j % kFoldDepth], std::false_type{}, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else if (!nofold) {
+        for (int i = first; i < first + P.corr_avg; ++i) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) x[0][r] = fetch(i, r);
+            fold_row(i, x[0], std::false_type{}, 0);
         }
     }
 
     // ---- per channel: apply V, FFT, x conj(R), FFT, statistics
-    const float inv_fs = 1.0f / (1000.0f * (float)cs);
-    const float sc = 1.0f / (float)P.corr_avg;
-#pragma unroll
-    for (int c = 0; c < CG; ++c) {
-        const StreamChan s = schan[c];
-        if (!s.active) continue;                                      // uniform over the workgroup
-        // V(m) for m = t + 256 r: base phasor and seven steps of 256 positions
-        const float f_eff = (float)((double)s.om * inv_2pi);
-        const float rev0 = fmaf(f_eff, (float)(t + 1) * inv_fs, s.ph * (float)inv_2pi);
-        float2 vm = phasor_rev(rev0);
+    // (1 / N of the inverse transform rides on the same factor: a power of two, so the
+    // magnitudes carry the same bits as when they are scaled at the end)
+    const float sc = (1.0f / (float)P.corr_avg) * (1.0f / kFftN);
+    // V(m) for m = t + 256 r (base phasor and seven steps of 256 positions) applied to the fold;
+    // the replica spectrum is fetched at the same time so that its latency hides behind the FFT
+    auto prepare = [&](int c, const StreamChan& s, float2 (&v)[8], float2 (&rs)[8]) {
+        float2 vm = cmulf(vtab[c][t & 15], vtab[c][16 + (t >> 4)]);
         const float2 st256 = step[c];
-        float2 v[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const float2 a = make_float2(acc[c][r].x * sc, acc[c][r].y * sc);
             v[r] = cmulf(a, vm);
             vm = cmulf(vm, st256);
         }
-        // the replica spectrum is fetched now so that its latency hides behind the FFT
         const float2* R = rep + (size_t)s.prn * kFftN;
-        float2 rs[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) rs[q] = R[t + 256 * q];
-        // (the two barriers of the previous channel's statistics already separate its
-        // last FFT reads from the writes below)
-        fft2048(v, lds, ftw, t);
+    };
+    auto times_conj = [&](float2 (&v)[8], const float2 (&rs)[8]) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const float2 x = v[q], r = rs[q];
             v[q] = make_float2(x.x * r.x + x.y * r.y, x.x * r.y - x.y * r.x);   // conj(x) * r
         }
+    };
+    auto magnitudes = [&](const float2 (&v)[8], float (&mag)[8]) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            mag[q] = __builtin_amdgcn_sqrtf(v[q].x * v[q].x + v[q].y * v[q].y);   // v_sqrt_f32, 1 ulp
+    };
+    // one channel through the transforms (the two barriers of the previous statistics already
+    // separate the last FFT reads from the writes of the next transform)
+    auto single = [&](int c) {
+        const StreamChan s = schan[c];
+        float2 v[8], rs[8];
+        prepare(c, s, v, rs);
+        fft2048(v, lds, ftw, t);
+        times_conj(v, rs);
         __syncthreads();
         fft2048(v, lds, ftw, t);
         float mag[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            mag[q] = sqrtf(v[q].x * v[q].x + v[q].y * v[q].y) * (1.0f / kFftN);
-
+        magnitudes(v, mag);
         // mean / std / first-index argmax over the 2048 lags, neighbours of the peak
         int bi; float bv, mean, sd, elo, ehi;
         corr_stats8(mag, t, magbuf, red, bi, bv, mean, sd, elo, ehi);
-        if (t == 0) {
-            const float norm = (bv - mean) / sd;
-            gpsmi_trk_out& o = out[s.job];
-            o.prn = s.prn;
-            o.mx = bi;
-            o.epl[0] = elo; o.epl[1] = bv; o.epl[2] = ehi;
-            o.corr_mean = mean; o.corr_std = sd;
-            o.norm_max_corr = norm;
-            int delay = -1;
-            double cp = -1.0;
-            if (norm > P.corr_min) {
-                delay = bi;
-                cp = fit_code_phase((double)elo, (double)bv, (double)ehi, bi);
-            }
-            o.delay = delay;
-            o.reserved0 = 0;
-            o.code_phase = cp;
-            int used = delay >= 0 ? delay : s.d;
-            if (delay_forced && delay_forced[s.job] >= 0) used = delay_forced[s.job];
-            o.delay_used = used;
-            JobMid md;
-            md.delay_used = used; md.active = 1; md.prn = s.prn; md.om = s.om; md.ph = s.ph;
-            md.pad[0] = md.pad[1] = md.pad[2] = 0;
-            mid[s.job] = md;
-        }
+        if (t == 0) fin[c] = CorrFin{bi, bv, mean, sd, elo, ehi};
+    };
+    if (P.flags & 64) {                          // diagnostics: no transforms
+        float sm = 0.f;
+#pragma unroll
+        for (int c = 0; c < CG; ++c)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) sm += acc[c][r].x + acc[c][r].y;
+        if (t < CG && schan[t].active)
+            corr_finish(schan[t], CorrFin{0, sm, 0.f, 1.f, 0.f, 0.f}, P, delay_forced, out, mid);
+        return;
     }
+#pragma unroll
+    for (int c = 0; c < CG; ++c)
+        if (schan[c].active) single(c);                                   // uniform over the workgroup
+    // the output records, one lane per channel (thread 0 wrote fin; the double-precision peak
+    // fit runs once per workgroup instead of once per channel on the first wave)
+    __syncthreads();
+    if (t < CG && schan[t].active) corr_finish(schan[t], fin[t], P, delay_forced, out, mid);
 }
 
 }  // namespace gpsmi
