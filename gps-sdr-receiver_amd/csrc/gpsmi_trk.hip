@@ -304,8 +304,16 @@ __global__ __launch_bounds__(256) void trk_epilogue_span_kernel(
     __shared__ float s_mag[40], s_dev[40], s_real[40], s_df[GPSMI_MAX_DF];
     __shared__ float q_hi[4][64], q_lo[4][64], s_hi[64], s_lo[64];
     __shared__ float2 s_S[GPSMI_MAX_DUMPS];
+    __shared__ gpsmi_trk_state s_si;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int job = blockIdx.x;
+    // the state row is requested with the job entry (one trip to memory for both) and waits in
+    // LDS for the per-job part
+    if (wave == 0) {
+        const int* a = reinterpret_cast<const int*>(&st_in[job]);
+        int* sa = reinterpret_cast<int*>(&s_si);
+        for (int i = lane; i < (int)(sizeof(gpsmi_trk_state) / 4); i += 64) sa[i] = a[i];
+    }
     const JobMid md = mid[job];
     if (!md.active) {
         if (wave == 0) epilogue_closed(st_in[job], st_out[job], out[job], st_out != st_in, lane);
@@ -323,7 +331,7 @@ __global__ __launch_bounds__(256) void trk_epilogue_span_kernel(
     __builtin_amdgcn_wave_barrier();
     span_windows(s_hi, s_lo, md.om, lane, s_S);
     __builtin_amdgcn_wave_barrier();
-    epilogue_job(st_in[job], st_out[job], md.delay_used, s_S, P, out[job], lane, s_mag, s_dev, s_real, s_df);
+    epilogue_job(s_si, st_out[job], md.delay_used, s_S, P, out[job], lane, s_mag, s_dev, s_real, s_df);
 }
 
 }  // namespace gpsmi

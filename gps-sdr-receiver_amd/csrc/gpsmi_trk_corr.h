@@ -22,7 +22,9 @@
 namespace gpsmi {
 
 // One channel's correlation result -> its output record and the correlator's job entry.
-constexpr int kFoldDepth = 3;      // rows of the fold in flight per workgroup
+// rows of the fold in flight per workgroup: three beside four channels' accumulators; all eight
+// when a workgroup serves one channel of one block (the closed loop: latency is all that counts)
+template <int CG> constexpr int kFoldDepthOf = CG == 1 ? 8 : 3;
 constexpr int kFoldChunk = 8;      // the row count the pipelined fold is written for (CORR_AVG of the reference)
 
 struct CorrFin { int bi; float bv, mean, sd, elo, ehi; };
@@ -60,7 +62,7 @@ __device__ __forceinline__ void corr_finish(const StreamChan& s, const CorrFin& 
 // (FMT 1: iq holds raw uint16 (Q << 8 | I) samples, decoded on load exactly as
 // gpsmi_dev_unpack_u8iq does)
 template <int CG, int FMT = 0>
-__global__ __launch_bounds__(256, CG > 4 ? 2 : 3) void trk_corr_kernel(
+__global__ __launch_bounds__(256, (CG > 4 || CG == 1) ? 2 : 3) void trk_corr_kernel(
     const void* __restrict__ iq, const gpsmi_trk_state* __restrict__ st_in,
     const int* __restrict__ delay_forced, const float2* __restrict__ rep,
     const float2* __restrict__ tw, TrkParams P, int ngroups, int nblocks,
@@ -90,6 +92,7 @@ __global__ __launch_bounds__(256, CG > 4 ? 2 : 3) void trk_corr_kernel(
     if (b >= nblocks) return;
     const int t = threadIdx.x;
     const int cs = kFftN;
+    constexpr int kFoldDepth = kFoldDepthOf<CG>;
     const float2* blk = static_cast<const float2*>(iq) + (size_t)b * ((size_t)cs * P.n_cyc);
     const uint16_t* rblk = static_cast<const uint16_t*>(iq) + (size_t)b * ((size_t)cs * P.n_cyc);
     const double inv_2pi = 0.15915494309189533576888376337251;
