@@ -454,12 +454,14 @@ def main():
         # beside the code-phase correlation of batch k and is over before the correlator
         # (the kernel the roofline is quoted for) starts
         acq.engine.after(trk)
-        acq.engine.search_async(d_iq0.ptr, acq_n, shard, acq_freqs, acq_navg, acq_pin.array,
-                                d_send.ptr if world > 1 else None)
         # the kernel-timing events of the other kernels are barrier packets in the queue
         # (~5 us each): the kernels of every fourth step are timed, the others run without
         trk.set_timing(k % TIMED_EVERY == 0)
+        # (the tracking batch goes into its queue first: its first kernel is what the GPU is
+        # waiting for when the host is late; the search has the whole of that kernel's time)
         trk.replay_run_async(d_iq.at(trk_base), nb)
+        acq.engine.search_async(d_iq0.ptr, acq_n, shard, acq_freqs, acq_navg, acq_pin.array,
+                                d_send.ptr if world > 1 else None)
         trk.replay_fetch_async(pins[k & 1].array)
         trk.wait_prev()
         if record and k > 0 and (k - 1) % TIMED_EVERY == 0:

@@ -178,7 +178,7 @@ struct gpsmi_acq {
 extern "C" int gpsmi_acq_wait(gpsmi_acq* h);
 
 namespace gpsmi {
-HandleSync acq_sync(gpsmi_acq* h) { return HandleSync{h->stream, h->order, h->cfg.device}; }
+HandleSync acq_sync(gpsmi_acq* h) { return HandleSync{h->stream, h->order, h->cfg.device, nullptr}; }
 }  // namespace gpsmi
 
 static int acq_reserve(gpsmi_acq* h, int nbins, int nsv) {
@@ -474,6 +474,10 @@ int gpsmi_acq_after_trk(gpsmi_acq* later, gpsmi_trk* earlier) {
     const HandleSync e = trk_sync(earlier);
     GPSMI_REQUIRE(e.device == later->cfg.device, "handles on different devices");
     GPSMI_HIP(hipSetDevice(e.device));
+    if (e.tail) {                         // (an event record is a barrier packet in the queue: reuse one)
+        GPSMI_HIP(hipStreamWaitEvent(later->stream, e.tail, 0));
+        return GPSMI_OK;
+    }
     GPSMI_HIP(hipEventRecord(e.order, e.stream));
     GPSMI_HIP(hipStreamWaitEvent(later->stream, e.order, 0));
     return GPSMI_OK;

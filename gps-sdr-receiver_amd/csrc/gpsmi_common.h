@@ -32,7 +32,8 @@ void make_twiddles(std::vector<float2>& tw);
 
 // stream of a handle and an event of its own to order another handle's stream behind it
 // (defined next to the handle structs; used by gpsmi_trk_after_acq / gpsmi_acq_after_trk)
-struct HandleSync { hipStream_t stream; hipEvent_t order; int device; };
+// `tail`: an event already recorded behind the last work on `stream` (null: record `order`)
+struct HandleSync { hipStream_t stream; hipEvent_t order; int device; hipEvent_t tail; };
 
 inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 

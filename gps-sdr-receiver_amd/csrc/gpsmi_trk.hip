@@ -346,6 +346,7 @@ struct gpsmi_trk {
     hipStream_t epi_stream = nullptr;    // replay: the epilogue of run k beside the code-phase
                                          // correlation of run k + 1 (the other slot's buffers)
     hipEvent_t order = nullptr;          // orders other handles' streams behind this one
+    hipEvent_t main_tail = nullptr;      // the event recorded behind the last work on `stream`, if any
     // two result slots: a replay run writes one while the other is still being copied out
     struct Slot {
         gpsmi_trk_out* d_out = nullptr;
@@ -445,6 +446,7 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
                       int njobs, int nch, bool side_epilogue = false) {
     TrkParams P = h->P;
     P.nch = nch;
+    h->main_tail = nullptr;
     const float2* d_iq = static_cast<const float2*>(d_iq_v);       // (raw uint16 when iq_fmt says so)
     const bool u8 = h->iq_fmt == GPSMI_IQ_U8;
     const bool timed = h->timing;        // each event record is a barrier packet (~5 us of bubble)
@@ -578,6 +580,7 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
     if (side_epilogue) {
         es = h->epi_stream;
         GPSMI_HIP(hipEventRecord(sl.corr_done, h->stream));
+        h->main_tail = sl.corr_done;          // (gpsmi_acq_after_trk orders the search behind this one)
         GPSMI_HIP(hipStreamWaitEvent(es, sl.corr_done, 0));
     }
     if (span_single)
@@ -597,7 +600,7 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
 
 namespace gpsmi {
 HandleSync acq_sync(gpsmi_acq* h);
-HandleSync trk_sync(gpsmi_trk* h) { return HandleSync{h->stream, h->order, h->cfg.device}; }
+HandleSync trk_sync(gpsmi_trk* h) { return HandleSync{h->stream, h->order, h->cfg.device, h->main_tail}; }
 }  // namespace gpsmi
 
 // kernel times of a finished launch into last_*_ms
@@ -993,6 +996,7 @@ int gpsmi_trk_wait_prev(gpsmi_trk* h) {
     if (sl.copy_pending) {
         GPSMI_HIP(hipEventSynchronize(sl.copied));
         sl.copy_pending = false;
+        sl.epi_pending = false;            // (the copy was queued behind the slot's epilogue)
     } else if (sl.timing_pending) {
         GPSMI_HIP(hipEventSynchronize(sl.ev[3]));
     }

@@ -262,7 +262,9 @@ int gpsmi_trk_wait_prev(gpsmi_trk* h);
 /* Device-side ordering between an acquisition and a tracking handle, no host wait:
  * what is enqueued on `later` after the call starts when everything enqueued on
  * `earlier` so far has finished (a search between two tracking batches without the
- * kernels of the two competing for the CUs).                                    */
+ * kernels of the two competing for the CUs).  Of an asynchronous replay batch that is its
+ * correlators: its epilogue and read-back run on streams of their own, beside what
+ * follows.                                                                        */
 int gpsmi_trk_after_acq(gpsmi_trk* later, gpsmi_acq* earlier);
 int gpsmi_acq_after_trk(gpsmi_acq* later, gpsmi_trk* earlier);
 /* State at the END of every job of the last replay, [nb][nch]: equals the next
