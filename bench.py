@@ -2,7 +2,7 @@
 """bench.py -- IQ Msamples/s ingested, 32-SV acquisition + 12-channel tracking.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--blocks NB]
-                    [--shard time|channels] [--no-cpu] [--no-extra]
+                    [--shard time|channels] [--no-cpu] [--no-extra] [--settle-steps S]
 
 Workload (BASELINE.json configs[2] with an acquisition search in front of it): a
 resident batch of NB 32-ms blocks of synthetic 2.048 Msps IQ (NB x 65536
@@ -22,6 +22,12 @@ step =
       evaluation differs (DESIGN.md "Closed loop and replay").
 value = NB * 65536 * n_gpus / step time.  The closed loop itself (state fed back
 block by block, launch-latency bound) is timed once and reported alongside.
+Before the W warm-up steps the device is driven with S = 300 (--settle-steps) of the
+same steps, untimed: an idle MI355X takes some 40 ms under load to reach steady clocks
+(the same correlator launch: ~120 us cold, 103 us from the 100th step on and flat for
+the 400 ms measured, profiles/round2/clock_settling.txt), and K = 20 steps timed from
+cold measure that ramp rather than the kernels.  S is printed in the JSON line;
+--settle-steps 0 gives the cold figure.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU).  Two splits of the
 tracking work (gpsmi/sharding.py):
@@ -262,6 +268,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--settle-steps', type=int, default=300,
+                    help='untimed steps ahead of the warm-up steps that bring the device to its '
+                         'steady clocks (see the module docstring); 0 = none')
     ap.add_argument('--blocks', type=int, default=1024)
     ap.add_argument('--cpu-blocks', type=int, default=192)
     ap.add_argument('--no-cpu', action='store_true')
@@ -467,6 +476,17 @@ def main():
         if record and k > 0 and (k - 1) % TIMED_EVERY == 0:
             record_last()
 
+    # Settling: an idle MI355X needs some 40 ms under load before its clocks stop moving - the
+    # same correlator launch takes ~120 us at the start of a run and ~103 us from the 100th
+    # step on, flat from there (profiles/round2/clock_settling.txt).  A 20-step timed region
+    # started cold would measure the ramp, not the kernels, so the device is first driven with
+    # the very step that is timed (a.settle_steps of them, the count is in the JSON line); the
+    # W warm-up steps and the K timed steps follow unchanged.
+    for k in range(a.settle_steps):
+        step(k, False)
+    if a.settle_steps:
+        finish_search()
+        trk.wait()
     for k in range(a.warmup):
         step(k, False)
     if a.warmup:
@@ -553,7 +573,7 @@ def main():
         line = {
             'metric': 'IQ Msamples/s ingested, 32-SV acq + 12-ch track',
             'value': round(value, 1), 'unit': 'Msamples/s', 'n_gpus': world,
-            'steps': a.steps, 'warmup': a.warmup,
+            'steps': a.steps, 'warmup': a.warmup, 'settle_steps': a.settle_steps,
             'ms_per_step': round(ms_step, 4), 'higher_is_better': True,
             'scaling': 'strong' if by_channel else 'weak', 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic',

@@ -18,7 +18,7 @@ os.makedirs(P, exist_ok=True)
 shutil.copy(R + 'bench_line.json', P + 'bench_line.json')
 shutil.copy(R + 'bench_prof_line.json', P + 'bench_line_under_rocprof.json')
 shutil.copy(newest(R + 'stats/*/*_kernel_stats.csv'), P + 'bench_kernel_stats.csv')
-for f in ('replay_pmc_counters.txt', 'kernel_bench.txt', 'span_prof.txt'):
+for f in ('replay_pmc_counters.txt', 'kernel_bench.txt', 'span_prof.txt', 'clock_settling.txt'):
     if os.path.exists(R + f):
         shutil.copy(R + f, P + f)
 md = P + 'bench_kernel_summary.md'

@@ -21,4 +21,7 @@ python3 tools/kernel_bench.py > $out/kernel_bench.txt 2>&1
 python3 tools/kernel_bench.py --delays aligned >> $out/kernel_bench.txt 2>&1
 python3 tools/kernel_bench.py --code-samples 16368 --n-cyc 8 --blocks 512 --iters 5 >> $out/kernel_bench.txt 2>&1
 find $out/stats -name "*kernel_stats.csv" -exec cp {} $out/bench_kernel_stats.csv \;
+# how the durations of the two big kernels drift from a cold start (no settling steps)
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $out/long -- python3 bench.py --no-cpu --no-extra --steps 1500 --warmup 5 --settle-steps 0 > $out/bench_cold_long.json 2> $out/bench_cold_long.err \
+  && python3 tools/span_series.py $out/long 50 > $out/clock_settling.txt; rm -rf $out/long
 cat $out/bench_line.json | cut -c1-300
