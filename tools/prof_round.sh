@@ -13,7 +13,7 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY 
            "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" \
            "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/pmc/pass$i -- python3 tools/kernel_bench.py --iters 3 > $out/pmc_pass$i.log 2>&1 || { echo "pmc pass $i failed"; tail -5 $out/pmc_pass$i.log; }
+  timeout -k 10 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/pmc/pass$i -- python3 tools/kernel_bench.py --iters 3 --settle 0 > $out/pmc_pass$i.log 2>&1 || { echo "pmc pass $i failed"; tail -5 $out/pmc_pass$i.log; }
 done
 python3 tools/pmc_summary.py $out/pmc > $out/replay_pmc_counters.txt
 tools/probe/span_prof 1024 > $out/span_prof.txt 2>&1 || echo "span_prof failed"
