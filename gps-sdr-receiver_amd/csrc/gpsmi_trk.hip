@@ -378,6 +378,7 @@ struct gpsmi_trk {
     int replay_nb = 0;
     bool replay_forced = false;
     int corr_cg = 4;
+    int done_by_dispatch = 1;          // GPSMI_DONE_BY_DISPATCH=0: an event record behind the correlator instead
     // code_samples != 2048: time-domain correlation + chunked correlator
     bool general = false;
     int stream_j = 8;                // code positions per lane of the correlator (8 or 4)
@@ -504,6 +505,7 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
     // trace reports), not event records around it: no barrier packets next to the kernel and
     // no launch gap inside the pair.
     const bool ext_timed = timed && h->mfma == 4 && !span_single;
+    bool corr_done_recorded = false;
     // batch form of the span correlator: persistent workgroups, two per CU, an equal number of
     // (block, channel group) units each
     const int span_units = nblocks * ng_span, span_slots = 2 * h->n_cu;
@@ -533,7 +535,20 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
             hipExtLaunchKernelGGL((trk_span_kernel<8, 4, 0, 0>), span_grid, dim3(256), 0, h->stream,
                                   sl.ev[1], sl.ev[2], 0, d_iq_v, (const JobMid*)sl.d_mid,
                                   (const float*)h->d_code_eo, P, ng12, nblocks, h->d_rec, sl.d_partial);
-        else if (h->mfma == 4 && u8)
+        else if (h->mfma == 4 && side_epilogue && h->done_by_dispatch) {
+            // replay: the event the epilogue stream (and a search) waits for is the completion
+            // signal of this very dispatch, not a record behind it - a record is one more
+            // barrier packet between this kernel and the next batch's first one
+            if (u8)
+                hipExtLaunchKernelGGL((trk_span_kernel<8, 4, 0, 1>), span_grid, dim3(256), 0, h->stream,
+                                      nullptr, sl.corr_done, 0, d_iq_v, (const JobMid*)sl.d_mid,
+                                      (const float*)h->d_code_eo, P, ng12, nblocks, h->d_rec, sl.d_partial);
+            else
+                hipExtLaunchKernelGGL((trk_span_kernel<8, 4, 0, 0>), span_grid, dim3(256), 0, h->stream,
+                                      nullptr, sl.corr_done, 0, d_iq_v, (const JobMid*)sl.d_mid,
+                                      (const float*)h->d_code_eo, P, ng12, nblocks, h->d_rec, sl.d_partial);
+            corr_done_recorded = true;
+        } else if (h->mfma == 4 && u8)
             hipLaunchKernelGGL((trk_span_kernel<8, 4, 0, 1>), span_grid, dim3(256), 0, h->stream,
                                d_iq_v, sl.d_mid, h->d_code_eo, P, ng12, nblocks, h->d_rec, sl.d_partial);
         else if (h->mfma == 4)
@@ -579,7 +594,7 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
     hipStream_t es = h->stream;
     if (side_epilogue) {
         es = h->epi_stream;
-        GPSMI_HIP(hipEventRecord(sl.corr_done, h->stream));
+        if (!corr_done_recorded) GPSMI_HIP(hipEventRecord(sl.corr_done, h->stream));
         h->main_tail = sl.corr_done;          // (gpsmi_acq_after_trk orders the search behind this one)
         GPSMI_HIP(hipStreamWaitEvent(es, sl.corr_done, 0));
     }
@@ -692,7 +707,7 @@ static int trk_build(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk* h) {
         for (auto& e : sl.ev) GPSMI_HIP(hipEventCreate(&e));
         GPSMI_HIP(hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming));
         GPSMI_HIP(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
-        GPSMI_HIP(hipEventCreateWithFlags(&sl.corr_done, hipEventDisableTiming));
+        GPSMI_HIP(hipEventCreate(&sl.corr_done));   // (also used as a dispatch's stop event)
         GPSMI_HIP(hipEventCreateWithFlags(&sl.epi_done, hipEventDisableTiming));
     }
     std::vector<float2> tw;
@@ -757,6 +772,7 @@ static int trk_build(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk* h) {
     P.flags = dbg ? atoi(dbg) : 0;
     const char* cgs = getenv("GPSMI_CORR_CG");
     if (cgs && (atoi(cgs) == 2 || atoi(cgs) == 4 || atoi(cgs) == 6)) h->corr_cg = atoi(cgs);
+    if (const char* dd = getenv("GPSMI_DONE_BY_DISPATCH")) h->done_by_dispatch = atoi(dd) != 0;
     return trk_reserve(h, max_ch);
 }
 
