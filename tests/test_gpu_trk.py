@@ -316,6 +316,50 @@ def test_pipelined_replay_runs_and_readbacks(closed_loop):
     assert all(g == outs.tobytes() for g in got)
 
 
+def test_search_ordered_behind_replay_batches(closed_loop):
+    """The step of bench.py: a search on its own handle ordered on the device behind the
+    previous batch's correlator (gpsmi_acq_after_trk: the dispatch's own completion event),
+    the batch's epilogue and read-back on their streams.  Every batch and every search must
+    return what the blocking calls return."""
+    from gpsmi.engine import AcqEngine, DeviceBuffer, PinnedArray, OUT_DTYPE, PEAK_DTYPE
+    eng, outs, states, blocks = closed_loop
+    nb, nch = outs.shape
+    buf = DeviceBuffer(nb * blocks[0].nbytes)
+    for i, b in enumerate(blocks):
+        buf.upload(b, i * b.nbytes)
+    eng.replay_load(nb, states, outs['delay_used'])
+    acq = AcqEngine()
+    prns = list(range(1, 33))
+    freqs = [-5000.0 + 250.0 * i for i in range(41)]
+    n = 2048
+    want = acq.search((buf.ptr, n), prns, freqs, 1)
+    pins = [PinnedArray((nb, nch), OUT_DTYPE) for _ in range(2)]
+    apins = [PinnedArray((len(freqs), len(prns)), PEAK_DTYPE) for _ in range(2)]
+    for k in range(5):
+        if k > 0:
+            acq.wait()
+            assert apins[(k - 1) & 1].array.tobytes() == want.tobytes(), k
+        pins[k & 1].array.view(np.uint8)[:] = 0xAB
+        apins[k & 1].array.view(np.uint8)[:] = 0xCD
+        acq.after(eng)
+        eng.set_timing(k % 2 == 0)
+        eng.replay_run_async(buf.ptr, nb)
+        acq.search_async(buf.ptr, n, prns, freqs, 1, apins[k & 1].array)
+        eng.replay_fetch_async(pins[k & 1].array)
+        eng.wait_prev()
+        if k > 0:
+            assert pins[(k - 1) & 1].array.tobytes() == outs.tobytes(), k
+    acq.wait()
+    eng.wait()
+    assert apins[4 & 1].array.tobytes() == want.tobytes()
+    assert pins[4 & 1].array.tobytes() == outs.tobytes()
+    eng.set_timing(True)
+    buf.free()
+    for p_ in pins + apins:
+        p_.free()
+    acq.close()
+
+
 @pytest.mark.parametrize('n_cyc', [16, 8])
 def test_other_block_lengths_match_the_oracle(n_cyc):
     """N_CYC = 16 and 8 at CODE_SAMPLES = 2048 (gpsglob.py:122 allows 8/16/32): no
