@@ -462,7 +462,7 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
     // ---- code-phase correlation
     if (h->general) {
         const int cs = P.cs;
-        hipLaunchKernelGGL(trk_fold_general_kernel, dim3((cs + 255) / 256, njobs), dim3(256), 0,
+        hipLaunchKernelGGL(trk_fold_general_kernel, dim3((cs + 255) / 256, nblocks), dim3(256), 0,
                            h->stream, d_iq, h->d_t32, st_in, P, h->d_fold, h->d_xsel, h->d_rsel,
                            sl.d_mid);
         if (h->big)

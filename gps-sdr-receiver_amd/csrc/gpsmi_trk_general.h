@@ -16,39 +16,89 @@
 
 namespace gpsmi {
 
+// One workgroup per (256 positions, block).  The wipe-off separates as in gpsmi_trk_corr.h:
+// for sample k = i cs + m, exp(-j(phase + w t[k])) = U[i] V(m) with U[i] = exp(-j w i T) uniform
+// over a row and V(m) = exp(-j(phase + w (m + 1) / fs)), so a sample costs one complex
+// multiply-accumulate per channel (instead of a sine and a cosine of a float32 argument of up
+// to ~1000 rad), every row is fetched from HBM once for all channels (the groups of four
+// re-read it from L1 / L2), and V is applied once per position and channel.
+constexpr int kGenFoldCh = 4;        // channels per pass over the rows
+
 __global__ __launch_bounds__(256) void trk_fold_general_kernel(
     const float2* __restrict__ iq, const float* __restrict__ t32,
     const gpsmi_trk_state* __restrict__ st_in, TrkParams P, float2* __restrict__ fold,
     int* __restrict__ xsel, int* __restrict__ rsel, JobMid* __restrict__ mid) {
-    const int job = blockIdx.y, m = blockIdx.x * 256 + threadIdx.x;
-    const int cs = P.cs, b = job / P.nch;
-    const gpsmi_trk_state& st = st_in[job];
-    const int active = st.prn > 0;
-    const float om = active ? (st.omega0 != 0.f ? st.omega0 : omega_of(st.freq)) : 0.f;
-    const float ph = st.phase;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        JobMid md;
-        md.delay_used = active ? st.delay : 0; md.active = active; md.prn = active ? st.prn : 0;
-        md.om = om; md.ph = active ? ph : 0.f;
-        md.pad[0] = md.pad[1] = md.pad[2] = 0;
-        mid[job] = md;
-        xsel[job] = job;
-        rsel[job] = md.prn;
-    }
-    if (m >= cs) return;
-    float2 acc = make_float2(0.f, 0.f);
-    if (active) {
-        const float2* blk = iq + (size_t)b * ((size_t)cs * P.n_cyc);
-        const int first = (P.n_cyc - P.corr_avg) / 2;
-        for (int i = first; i < first + P.corr_avg; ++i) {
-            const int k = i * cs + m;
-            const float2 y = wipe(blk[k], ph, om, t32[k]);
-            acc.x += y.x; acc.y += y.y;
+    (void)t32;
+    __shared__ float2 urow[kGenFoldCh][32];              // corr_avg <= n_cyc <= 32
+    __shared__ float s_om[kGenFoldCh], s_ph[kGenFoldCh];
+    __shared__ int s_active[kGenFoldCh];
+    const int b = blockIdx.y, t = threadIdx.x, m = blockIdx.x * 256 + t;
+    const int cs = P.cs, nch = P.nch;
+    const int first = (P.n_cyc - P.corr_avg) / 2;
+    const double inv_2pi = 0.15915494309189533576888376337251;
+    const float2* blk = iq + (size_t)b * ((size_t)cs * P.n_cyc) + (size_t)first * cs + (m < cs ? m : 0);
+    const float sc = 1.0f / (float)P.corr_avg;
+    const float tm = (float)(m + 1) / (1000.0f * (float)cs);              // (m + 1) / fs
+    for (int c0 = 0; c0 < nch; c0 += kGenFoldCh) {
+        // ---- the group's constants and job descriptors
+        if (t < kGenFoldCh) {
+            const int ch = c0 + t;
+            int active = 0;
+            float om = 0.f, ph = 0.f;
+            if (ch < nch) {
+                const int job = b * nch + ch;
+                const gpsmi_trk_state& st = st_in[job];
+                active = st.prn > 0;
+                om = active ? (st.omega0 != 0.f ? st.omega0 : omega_of(st.freq)) : 0.f;
+                ph = active ? st.phase : 0.f;
+                if (blockIdx.x == 0) {
+                    JobMid md;
+                    md.delay_used = active ? st.delay : 0; md.active = active; md.prn = active ? st.prn : 0;
+                    md.om = om; md.ph = ph;
+                    md.pad[0] = md.pad[1] = md.pad[2] = 0;
+                    mid[job] = md;
+                    xsel[job] = job;
+                    rsel[job] = md.prn;
+                }
+            }
+            s_om[t] = om; s_ph[t] = ph; s_active[t] = active;
         }
-        const float sc = 1.0f / (float)P.corr_avg;
-        acc.x *= sc; acc.y *= sc;
+        __syncthreads();
+        if (t < kGenFoldCh * P.corr_avg) {
+            const int c = t / P.corr_avg, i = t % P.corr_avg;
+            const double rev = (double)s_om[c] * inv_2pi * (double)(first + i) * 1.0e-3;   // w i T / 2 pi
+            urow[c][i] = phasor_rev((float)(rev - rint(rev)));
+        }
+        __syncthreads();
+        if (m < cs) {
+            float2 acc[kGenFoldCh];
+#pragma unroll
+            for (int c = 0; c < kGenFoldCh; ++c) acc[c] = make_float2(0.f, 0.f);
+            for (int i = 0; i < P.corr_avg; ++i) {
+                const float2 x = blk[(size_t)i * cs];
+#pragma unroll
+                for (int c = 0; c < kGenFoldCh; ++c) {
+                    const float2 u = urow[c][i];
+                    acc[c].x = fmaf(u.x, x.x, fmaf(-u.y, x.y, acc[c].x));
+                    acc[c].y = fmaf(u.x, x.y, fmaf(u.y, x.x, acc[c].y));
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < kGenFoldCh; ++c) {
+                const int ch = c0 + c;
+                if (ch < nch) {
+                    float2 r = make_float2(0.f, 0.f);
+                    if (s_active[c]) {
+                        const float f_eff = (float)((double)s_om[c] * inv_2pi);
+                        const float2 v = phasor_rev(fmaf(f_eff, tm, s_ph[c] * (float)inv_2pi));
+                        r = cmulf(make_float2(acc[c].x * sc, acc[c].y * sc), v);
+                    }
+                    fold[(size_t)(b * nch + ch) * cs + m] = r;
+                }
+            }
+        }
+        __syncthreads();                                   // (the tables are rewritten for the next group)
     }
-    fold[(size_t)job * cs + m] = acc;
 }
 
 __global__ void trk_decide_kernel(const DirStats* __restrict__ stats,
