@@ -394,6 +394,53 @@ def test_other_block_lengths_match_the_oracle(n_cyc):
     eng.close()
 
 
+@pytest.mark.parametrize('corr_avg', [4, 5, 12])
+def test_other_corr_avg_matches_the_oracle(corr_avg):
+    """CORR_AVG other than the reference's 8 (gpsglob.py:63): the code-phase correlation
+    then folds its rows one at a time instead of through the eight-row pipeline; compared
+    with the oracle on a fresh scene, closed loop and replay."""
+    import gps_oracle as orc
+    from gpsmi import synth
+    from gpsmi.engine import Config, TrkEngine, DeviceBuffer, STATE_DTYPE, dumps_of
+    p = orc.Params(corr_avg=corr_avg)
+    sc = synth.default_scene(5, seed=77 + corr_avg, amp=0.09)
+    nb = 6
+    blocks = [sc.block(b) for b in range(nb)]
+    nch = len(sc.sats)
+    eng = TrkEngine(Config(corr_avg=corr_avg), max_ch=nch)
+    streams = []
+    for c, s in enumerate(sc.sats):
+        f0 = round(s.doppler / 200.0) * 200.0
+        d0 = int(round(s.delay)) % 2048
+        eng.open(c, s.prn, f0, d0)
+        streams.append(orc.SatStream(s.prn, f0, p, delay=d0))
+    outs, states = [], []
+    for i, blk in enumerate(blocks):
+        st = np.zeros(nch, dtype=STATE_DTYPE)
+        for c in range(nch):
+            st[c] = eng.get_state(c)
+        states.append(st)
+        out = eng.process(blk)
+        outs.append(out)
+        for c, ss in enumerate(streams):
+            ss.process(blk, np.int64((i + 1) * p.ngps))
+            where = f'corr_avg {corr_avg} channel {c} block {i}'
+            assert out[c]['mx'] == ss.last['mx'], where
+            assert out[c]['delay_used'] == ss.delay, where
+            np.testing.assert_allclose(out[c]['epl'], ss.last['epl'], rtol=1e-3, err_msg=where)
+            np.testing.assert_allclose(dumps_of(out[c]), ss.last['dumps'], rtol=1e-3,
+                                       atol=1e-5, err_msg=where)
+            assert abs(out[c]['freq'] - ss.freq) < 0.05, where
+    outs, states = np.array(outs), np.array(states)
+    buf = DeviceBuffer(nb * blocks[0].nbytes)
+    for i, b in enumerate(blocks):
+        buf.upload(b, i * b.nbytes)
+    rep = eng.replay(buf.ptr, nb, states, outs['delay_used'])      # four-channel form of the kernel
+    buf.free()
+    eng.close()
+    assert rep.tobytes() == outs.tobytes()
+
+
 def test_twenty_channels_four_groups():
     """More channels than the reference's MAX_SAT: 20 channels = four workgroup groups of
     the correlator, five groups of the correlation kernel; every channel equals the same
