@@ -497,14 +497,15 @@ def test_code_length_4096_matches_the_oracle():
     assert np.array_equal(tab['argmax'], ref['argmax'])
     for k in ('peak', 'mean', 'std'):
         np.testing.assert_allclose(tab[k], ref[k], rtol=1e-4)
-    eng = TrkEngine(cfg, max_ch=len(sc.sats))
-    streams = []
+    eng = TrkEngine(cfg, max_ch=len(sc.sats) + 3)        # three channels stay closed: the fold's
+    streams = []                                           # second group of four is 1 open + 2 closed + padding
     for c, s in enumerate(sc.sats):
         d0 = int(tab['argmax'][c, c])
         eng.open(c, s.prn, freqs[c], d0)
         streams.append(orc.SatStream(s.prn, freqs[c], p, delay=d0))
     for i, blk in enumerate(blocks[1:], start=1):
         out = eng.process(blk)
+        assert all(out[c]['prn'] == 0 and out[c]['n_dumps'] == 0 for c in range(len(sc.sats), len(out)))
         for c, ss in enumerate(streams):
             ss.process(blk, np.int64((i + 1) * p.ngps))
             where = f'channel {c} block {i}'
