@@ -5,15 +5,17 @@
 // The reference wipes the carrier off the centre corr_avg code periods, sums
 // their FFTs, multiplies by conj(FFT(replica)) and takes |ifft|.  Here the sum
 // of FFTs is the FFT of the sum, and the wipe-off separates exactly as in the
-// correlator (gpsmi_trk_stream.h): for sample k = i*CS + m
+// correlator (gpsmi_trk_span.h): for sample k = i*CS + m
 //     exp(-j(phase + w (k+1)/fs)) = V(m) * U[i],  U[i] = exp(-j w i T),
 // so fold[m] = V(m) * sum_i U[i] x[i][m]: one complex multiply-accumulate per
-// channel-sample with a wave-uniform U, every sample loaded once for the six
+// channel-sample with a wave-uniform U, every sample loaded once for the CG
 // channels; V is applied once per position.  Then, per channel, two passes of
 // the LDS-resident 2048-point FFT (the second one as the inverse), |.|, mean /
-// population std / first-index argmax, the two neighbours of the peak, and
-// thread 0 applies the CORR_MIN threshold, the peak fit and chooses the DELAY
-// the block is decoded with (gpslib.py:1181-1182).
+// population std / first-index argmax and the two neighbours of the peak; at the
+// end one lane per channel applies the CORR_MIN threshold and the peak fit and
+// chooses the DELAY the block is decoded with (gpslib.py:1181-1182).
+// DESIGN.md section 4.4 has the measurements behind the structure (what the
+// prologue requests at once, the three-deep row pipeline, the LDS tables of V).
 #pragma once
 #include <type_traits>
 #include "gpsmi_fft.h"
@@ -21,12 +23,13 @@
 
 namespace gpsmi {
 
-// One channel's correlation result -> its output record and the correlator's job entry.
 // rows of the fold in flight per workgroup: three beside four channels' accumulators; all eight
 // when a workgroup serves one channel of one block (the closed loop: latency is all that counts)
 template <int CG> constexpr int kFoldDepthOf = CG == 1 ? 8 : 3;
 constexpr int kFoldChunk = 8;      // the row count the pipelined fold is written for (CORR_AVG of the reference)
 
+// One channel's correlation result (thread 0 parks it in LDS), and its way into the output
+// record and the correlator's job entry.
 struct CorrFin { int bi; float bv, mean, sd, elo, ehi; };
 
 __device__ __forceinline__ void corr_finish(const StreamChan& s, const CorrFin& f, const TrkParams& P,
@@ -72,11 +75,10 @@ __global__ __launch_bounds__(256, (CG > 4 || CG == 1) ? 2 : 3) void trk_corr_ker
     __shared__ float red[kStatsRedFloats];
     // Two small arrays live inside the second FFT buffer, which a transform leaves free when it
     // returns and does not write before its first barrier: the magnitudes of the statistics
-    // (8 KiB) and the row factors of the fold (1 KiB, used before any transform).  40.1 KiB of
-    // LDS per workgroup instead of 49.3, so LDS no longer limits the kernel to three workgroups
-    // per CU; the registers still do for CG = 4 (166 VGPRs), and CG = 2 (126 VGPRs, four
-    // workgroups per CU, the fold's rows read six times per block instead of three) measured
-    // 3-4 % slower per batch.
+    // (8 KiB) and the row factors of the fold (1 KiB, used before any transform).  41.2 KiB of
+    // LDS per workgroup, three workgroups per CU at CG = 4 by the registers (162 VGPRs, capped
+    // at 168 by the launch bounds); CG = 2 (four workgroups per CU, the fold's rows read six
+    // times per block instead of three) measured 10 % slower per batch.
     float* magbuf = lds + 2 * kFftPlane;
     float2 (*urow)[32] = reinterpret_cast<float2 (*)[32]>(lds + 2 * kFftPlane);   // U[c][i], i = row
     static_assert(kFftN <= 2 * kFftPlane1 && CG * 32 * 2 <= 2 * kFftPlane1, "aliases must fit buffer 1");
