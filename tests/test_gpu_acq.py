@@ -167,3 +167,34 @@ def test_hirate_sweep_all_sats_loop(acq_hirate, golden_hirate):
     ref = g['sweep_found']
     assert np.array_equal(mine[:, 1:], ref[:, 1:])
     np.testing.assert_allclose(mine[:, 0], ref[:, 0], rtol=RTOL)
+
+
+def test_rccl_gather_of_peak_records_single_rank(acq, golden_default):
+    """The multi-GPU exchange with a world of one: unique id -> communicator -> a search that
+    leaves its peak records in device memory -> gpsmi_comm_allgather_peaks (RCCL all-gather
+    on the device, copy to the host).  What arrives must be the search's own table."""
+    import ctypes as C
+    from gpsmi import _lib
+    from gpsmi.engine import DeviceBuffer, PEAK_DTYPE, check, ptr
+    lib = _lib.load()
+    idb = np.zeros(128, dtype=np.uint8)
+    check(lib.gpsmi_comm_unique_id(ptr(idb)), 'gpsmi_comm_unique_id')
+    comm = C.c_void_p()
+    check(lib.gpsmi_comm_create(ptr(idb), 1, 0, 0, C.byref(comm)), 'gpsmi_comm_create')
+    prns = list(range(1, 33))
+    freqs = [-5000.0 + 250.0 * i for i in range(41)]
+    blk = scene_blocks('default', 0, 1)[0]
+    d_iq = DeviceBuffer(blk.nbytes)
+    d_iq.upload(blk, 0)
+    cells = len(prns) * len(freqs)
+    d_send = DeviceBuffer(cells * PEAK_DTYPE.itemsize)
+    d_recv = DeviceBuffer(cells * PEAK_DTYPE.itemsize)
+    table = acq.engine.search((d_iq.ptr, 2048), prns, freqs, 1, out_dev=d_send.ptr)
+    got = np.zeros((len(freqs), len(prns)), dtype=PEAK_DTYPE)
+    check(lib.gpsmi_comm_allgather_peaks(comm, d_send.ptr, d_recv.ptr, cells, ptr(got)),
+          'gpsmi_comm_allgather_peaks')
+    check(lib.gpsmi_comm_destroy(comm), 'gpsmi_comm_destroy')
+    for b in (d_iq, d_send, d_recv):
+        b.free()
+    assert got.tobytes() == table.tobytes()
+    assert np.array_equal(table['argmax'], golden_default['cfg2_argmax'])
