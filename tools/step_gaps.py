@@ -10,12 +10,12 @@ corrs=[r for r in rows if r[2].startswith('trk_corr_kernel<4, 0>')]
 import bisect
 cs=[c[0] for c in corrs]
 gaps=[];cd=[];sd=[];per=[]
-for sp in spans[20:100]:
+for sp in spans[-101:-1]:                 # the timed region: the last launches of the run
     i=bisect.bisect_left(cs,sp[1]-1000)
     if i<len(corrs):
         gaps.append((corrs[i][0]-sp[1])/1e3)
     sd.append((sp[1]-sp[0])/1e3)
-for a,b in zip(spans[20:99],spans[21:100]): per.append((b[0]-a[0])/1e3)
-for c in corrs[20:100]: cd.append((c[1]-c[0])/1e3)
+for a,b in zip(spans[-101:-2],spans[-100:-1]): per.append((b[0]-a[0])/1e3)
+for c in corrs[-101:-1]: cd.append((c[1]-c[0])/1e3)
 import statistics as st
 print('gap span->next corr: median %.1f'%st.median(gaps),'span %.1f'%st.median(sd),'corr %.1f'%st.median(cd),'period %.1f'%st.median(per))
