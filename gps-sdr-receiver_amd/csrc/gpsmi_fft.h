@@ -63,6 +63,15 @@ __device__ __forceinline__ fft_c cmulp(fft_c a, fft_c w) {
     return d;
 }
 
+// conj(a) * w, packed the same way
+__device__ __forceinline__ fft_c cmulp_conj(fft_c a, fft_c w) {
+    fft_c d;
+    asm("v_pk_mul_f32 %0, %2, %1 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %2, %1, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+        : "=&v"(d) : "v"(a), "v"(w));
+    return d;
+}
+
 // 4-point DFT, Y[k] = sum_n b[n] (-i)^(nk), in place, natural order.  With B2MI the
 // input b2 still lacks its factor -i (folded into the first two adds).
 template <bool B2MI>

@@ -201,9 +201,15 @@ __global__ __launch_bounds__(256, (CG > 4 || CG == 1) ? 2 : 3) void trk_corr_ker
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const v2f xr = decode(xk[r]);
-            if constexpr (decltype(reload)::value) xk[r] = fetch(inext, r);
             fold_in(u, r, xr, xprev);
             xprev = xr;
+            // (reloaded behind its last use: requested ahead of it, the old value needs a copy)
+            if constexpr (decltype(reload)::value) {
+                if (CG > 1 || (r & 1)) {
+                    xk[r] = fetch(inext, r);
+                    if (CG == 1) xk[r - 1] = fetch(inext, r - 1);
+                }
+            }
         }
     };
     if (piped) {
@@ -230,13 +236,14 @@ __global__ __launch_bounds__(256, (CG > 4 || CG == 1) ? 2 : 3) void trk_corr_ker
     // V(m) for m = t + 256 r (base phasor and seven steps of 256 positions) applied to the fold;
     // the replica spectrum is fetched at the same time so that its latency hides behind the FFT
     auto prepare = [&](int c, const StreamChan& s, float2 (&v)[8], float2 (&rs)[8]) {
-        float2 vm = cmulf(vtab[c][t & 15], vtab[c][16 + (t >> 4)]);
-        const float2 st256 = step[c];
+        const float2 e1 = vtab[c][t & 15], e2 = vtab[c][16 + (t >> 4)], s2 = step[c];
+        fft_c vm = cmulp(fft_c{e1.x, e1.y}, fft_c{e2.x, e2.y});
+        const fft_c st256 = fft_c{s2.x, s2.y};
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            const float2 a = make_float2(acc[c][r].x * sc, acc[c][r].y * sc);
-            v[r] = cmulf(a, vm);
-            vm = cmulf(vm, st256);
+            const fft_c o = cmulp(acc[c][r] * sc, vm);                // (packed: two instructions each)
+            v[r] = make_float2(o.x, o.y);
+            vm = cmulp(vm, st256);
         }
         const float2* R = rep + (size_t)s.prn * kFftN;
 #pragma unroll
@@ -245,8 +252,8 @@ __global__ __launch_bounds__(256, (CG > 4 || CG == 1) ? 2 : 3) void trk_corr_ker
     auto times_conj = [&](float2 (&v)[8], const float2 (&rs)[8]) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const float2 x = v[q], r = rs[q];
-            v[q] = make_float2(x.x * r.x + x.y * r.y, x.x * r.y - x.y * r.x);   // conj(x) * r
+            const fft_c o = cmulp_conj(fft_c{v[q].x, v[q].y}, fft_c{rs[q].x, rs[q].y});   // conj(x) * r
+            v[q] = make_float2(o.x, o.y);
         }
     };
     auto magnitudes = [&](const float2 (&v)[8], float (&mag)[8]) {
