@@ -28,19 +28,25 @@
 namespace gpsmi {
 
 // ---- kernels ---------------------------------------------------------------
-__global__ __launch_bounds__(256) void acq_spectrum_kernel(
+// G = 1: 256 threads, the code periods folded one after the other.  G = 4 (long coherent
+// searches): 1024 threads, the periods dealt round-robin to four groups of 256 whose partial
+// folds meet in LDS (the sine / cosine per sample is what this kernel spends its time on);
+// group 0 then adds them in group order and transforms.
+template <int G>
+__global__ __launch_bounds__(256 * G) void acq_spectrum_kernel(
     const float2* __restrict__ iq, const float* __restrict__ t32,
     const float* __restrict__ omega, int n_avg, float2* __restrict__ spectra,
     const float2* __restrict__ tw) {
     __shared__ __attribute__((aligned(16))) float lds[kFftLdsFloats];
     __shared__ __attribute__((aligned(16))) float lds_tw[kFftTwFloats];
-    const int t = threadIdx.x, bin = blockIdx.x;
-    const FftTw ftw = fft_setup(lds_tw, tw, t);
+    __shared__ float2 part[G > 1 ? G - 1 : 1][G > 1 ? kFftN : 1];
+    const int t = threadIdx.x & 255, grp = threadIdx.x >> 8, bin = blockIdx.x;
+    const FftTw ftw = fft_setup(lds_tw, tw, t);           // (every group writes the same tables)
     const float om = omega[bin];
     float2 v[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] = make_float2(0.f, 0.f);
-    for (int i = 0; i < n_avg; ++i) {
+    for (int i = grp; i < n_avg; i += G) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             int k = i * kFftN + t + 256 * r;
@@ -52,6 +58,21 @@ __global__ __launch_bounds__(256) void acq_spectrum_kernel(
             v[r].x += c * x.x + s * x.y;
             v[r].y += c * x.y - s * x.x;
         }
+    }
+    if (G > 1) {
+        if (grp > 0) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) part[grp - 1][t + 256 * r] = v[r];
+        }
+        __syncthreads();
+        if (grp > 0) return;                   // (a wave that has ended no longer counts at a barrier)
+#pragma unroll
+        for (int g = 1; g < G; ++g)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float2 o = part[g - 1][t + 256 * r];
+                v[r].x += o.x; v[r].y += o.y;
+            }
     }
     __syncthreads();
     fft2048(v, lds, ftw, t);
@@ -398,8 +419,12 @@ static int acq_search_impl(gpsmi_acq* h, const void* d_iq, size_t n, const int32
         hipLaunchKernelGGL(acq_peaks_kernel, dim3((ncell + 255) / 256), dim3(256), 0, h->stream,
                            h->d_stats, h->d_peaks, nbr ? h->d_nbr : nullptr, ncell);
     } else {
-        hipLaunchKernelGGL(acq_spectrum_kernel, dim3(nbins), dim3(256), 0, h->stream,
-                           (const float2*)d_iq, h->d_t32, h->d_omega, n_avg, h->d_spec, h->d_tw);
+        if (n_avg >= 4)
+            hipLaunchKernelGGL(acq_spectrum_kernel<4>, dim3(nbins), dim3(1024), 0, h->stream,
+                               (const float2*)d_iq, h->d_t32, h->d_omega, n_avg, h->d_spec, h->d_tw);
+        else
+            hipLaunchKernelGGL(acq_spectrum_kernel<1>, dim3(nbins), dim3(256), 0, h->stream,
+                               (const float2*)d_iq, h->d_t32, h->d_omega, n_avg, h->d_spec, h->d_tw);
         hipLaunchKernelGGL(acq_corr_kernel, dim3(nsv, nbins), dim3(256), 0, h->stream, h->d_spec,
                            h->d_rep, h->d_slot, h->d_peaks, nsv, h->d_tw,
                            nbr ? h->d_nbr : nullptr);
