@@ -21,6 +21,7 @@
 
 #include "gpsmi_common.h"
 #include "gpsmi_bigfft.h"
+#include "gpsmi_pfa.h"
 #include "gpsmi_direct.h"
 #include "gpsmi_fft.h"
 #include "gpsmi_stats.h"
@@ -195,6 +196,9 @@ struct gpsmi_acq {
     // ... through one 32768-point FFT pair when the code period fits (gpsmi_bigfft.h)
     bool big = false;
     float2* d_twN = nullptr; float2* d_RS = nullptr; float2* d_S = nullptr;
+    // ... or natively in LDS when the code period is 16368 = 16 * 3 * 11 * 31 samples (gpsmi_pfa.h)
+    bool pfa = false;
+    float2* d_RSp = nullptr;                // [GPSMI_MAX_PRN + 1][16368] replica spectra, P3's order
     float last_ms = 0.f;
     bool pending = false;
 };
@@ -280,8 +284,15 @@ static int acq_build(const gpsmi_cfg* cfg, gpsmi_acq* h) {
     if (h->direct) {
         GPSMI_HIP(hipMalloc((void**)&h->d_rep_time,
                             (size_t)(GPSMI_MAX_PRN + 1) * cfg->code_samples * sizeof(float)));
-        const char* force = getenv("GPSMI_DIRECT_CORR");          // 1: keep the time-domain kernel
-        h->big = 2 * cfg->code_samples - 1 <= kBigN && !(force && atoi(force) == 1);
+        const char* force = getenv("GPSMI_DIRECT_CORR");          // 1: keep the time-domain kernel,
+        const int forced = force ? atoi(force) : 0;               // 2: the zero-padded 32768-point pair
+        h->pfa = cfg->code_samples == kPfaL && forced == 0;
+        h->big = !h->pfa && 2 * cfg->code_samples - 1 <= kBigN && forced != 1;
+        if (h->pfa) {
+            const size_t b = (size_t)(GPSMI_MAX_PRN + 1) * kPfaL * sizeof(float2);
+            GPSMI_HIP(hipMalloc((void**)&h->d_RSp, b));
+            GPSMI_HIP(hipMemset(h->d_RSp, 0, b));
+        }
         if (h->big) {
             std::vector<float2> twn(kBigN);
             for (int k = 0; k < kBigN; ++k) {
@@ -305,7 +316,7 @@ int gpsmi_acq_destroy(gpsmi_acq* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* bufs[] = {h->d_tw, h->d_t32, h->d_rep, h->d_iq, h->d_spec, h->d_omega, h->d_slot,
                     h->d_peaks, h->d_nbr, h->d_rep_time, h->d_fold, h->d_mag, h->d_stats,
-                    h->d_xsel, h->d_rsel, h->d_twN, h->d_RS, h->d_S};
+                    h->d_xsel, h->d_rsel, h->d_twN, h->d_RS, h->d_S, h->d_RSp};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (int k = 0; k < 2; ++k) {
@@ -328,9 +339,11 @@ int gpsmi_acq_set_replica_time(gpsmi_acq* h, int prn, const float* replica) {
     GPSMI_HIP(hipSetDevice(h->cfg.device));
     GPSMI_HIP(hipMemcpy(h->d_rep_time + (size_t)prn * h->cfg.code_samples, replica,
                         (size_t)h->cfg.code_samples * sizeof(float), hipMemcpyHostToDevice));
-    if (h->big) {
+    if (h->big)
         big_replica_launch(h->stream, h->d_rep_time, prn, h->cfg.code_samples, h->d_RS, h->d_tw,
                            h->d_twN);
+    if (h->pfa) pfa_replica_launch(h->stream, h->d_rep_time, prn, h->d_RSp);
+    if (h->big || h->pfa) {
         GPSMI_HIP(hipGetLastError());
         GPSMI_HIP(hipStreamSynchronize(h->stream));
     }
@@ -395,7 +408,7 @@ static int acq_search_impl(gpsmi_acq* h, const void* d_iq, size_t n, const int32
                 if (p) GPSMI_HIP(hipFree(p));
             h->d_mag = nullptr; h->d_stats = nullptr; h->d_xsel = h->d_rsel = nullptr;
             h->dir_cells = 0;
-            GPSMI_HIP(hipMalloc((void**)&h->d_mag, cells * cs * sizeof(float)));
+            if (!h->pfa) GPSMI_HIP(hipMalloc((void**)&h->d_mag, cells * cs * sizeof(float)));
             GPSMI_HIP(hipMalloc((void**)&h->d_stats, cells * sizeof(DirStats)));
             GPSMI_HIP(hipMalloc((void**)&h->d_xsel, cells * sizeof(int)));
             GPSMI_HIP(hipMalloc((void**)&h->d_rsel, cells * sizeof(int)));
@@ -409,7 +422,9 @@ static int acq_search_impl(gpsmi_acq* h, const void* d_iq, size_t n, const int32
                            (const float2*)d_iq, h->d_t32, h->d_omega, n_avg, cs, h->d_fold);
         hipLaunchKernelGGL(acq_cells_kernel, dim3((ncell + 255) / 256), dim3(256), 0, h->stream,
                            h->d_xsel, h->d_rsel, h->d_slot, nsv, ncell);
-        if (h->big)
+        if (h->pfa)              // transform, product, transform and statistics in one launch
+            pfa_corr_launch(h->stream, h->d_fold, h->d_xsel, h->d_rsel, ncell, h->d_RSp, h->d_stats);
+        else if (h->big)
             big_corr_launch(h->stream, h->d_fold, h->d_xsel, h->d_rsel, ncell, cs, h->d_RS, h->d_S,
                             h->d_tw, h->d_twN, h->d_mag);
         else
@@ -417,8 +432,9 @@ static int acq_search_impl(gpsmi_acq* h, const void* d_iq, size_t n, const int32
                                dim3((cs + kDirLagsPerWg - 1) / kDirLagsPerWg, ncell), dim3(256), 0,
                                h->stream, h->d_fold, h->d_rep_time, h->d_xsel, h->d_rsel, cs,
                                h->d_mag);
-        hipLaunchKernelGGL(corr_stats_kernel, dim3(ncell), dim3(256), 0, h->stream, h->d_mag, cs,
-                           h->d_stats);
+        if (!h->pfa)
+            hipLaunchKernelGGL(corr_stats_kernel, dim3(ncell), dim3(256), 0, h->stream, h->d_mag, cs,
+                               h->d_stats);
         hipLaunchKernelGGL(acq_peaks_kernel, dim3((ncell + 255) / 256), dim3(256), 0, h->stream,
                            h->d_stats, h->d_peaks, nbr ? h->d_nbr : nullptr, ncell);
     } else {

@@ -112,6 +112,7 @@ __device__ inline double fit_code_phase(double lo, double pk, double hi, int mx)
 #include "gpsmi_trk_stream_mfma.h"
 #include "gpsmi_trk_corr.h"
 #include "gpsmi_bigfft.h"
+#include "gpsmi_pfa.h"
 #include "gpsmi_trk_general.h"
 #pragma clang fp contract(off)
 #include "gpsmi_trk_span.h"
@@ -356,6 +357,9 @@ struct gpsmi_trk {
         bool copy_pending = false, timing_pending = false, epi_pending = false;
         JobMid* d_mid = nullptr;             // per-job descriptors and window sums of the slot's run
         float2* d_partial = nullptr;
+        float* d_rec = nullptr;              // raw sums of the single-block span correlator (gpsmi_trk_span.h):
+                                             // per slot, the epilogue of run k reads them on its own stream
+                                             // while run k + 1 writes the other slot's
     } slot[2];
     int cur = 0;                         // slot of the latest launch
     bool timing = true;                  // record the four kernel-timing events per launch
@@ -388,7 +392,6 @@ struct gpsmi_trk {
     float* d_code2 = nullptr;        // [GPSMI_MAX_PRN + 1][2 cs]: replica twice (no index wrap)
     float* d_code_eo = nullptr;      // [GPSMI_MAX_PRN + 1][2][cs]: replica split by index parity, each
                                      // plane twice (span form)
-    float* d_rec = nullptr;          // raw sums of the span correlator's waves (gpsmi_trk_span.h)
     int n_cu = 256;                  // compute units of the device
     int iq_fmt = GPSMI_IQ_C64;       // what the iq pointers of process / replay point to
     int nchunks = 1;                 // spans of 256 * stream_j positions per code period
@@ -396,6 +399,8 @@ struct gpsmi_trk {
     int* d_xsel = nullptr; int* d_rsel = nullptr; float2* d_partial_g = nullptr;
     bool big = false;                // correlation through the 32768-point FFT pair
     float2* d_twN = nullptr; float2* d_RS = nullptr; float2* d_S = nullptr;
+    bool pfa = false;                // ... or natively in LDS at 16368 samples (gpsmi_pfa.h)
+    float2* d_RSp = nullptr;
     TrkParams P;
 };
 
@@ -405,23 +410,22 @@ static int trk_reserve(gpsmi_trk* h, size_t njobs) {
     if (njobs <= h->njobs_cap) return GPSMI_OK;
     void* olds[] = {h->d_tab_in, h->d_tab_out, h->d_forced, h->slot[0].d_mid, h->slot[1].d_mid,
                     h->slot[0].d_partial, h->slot[1].d_partial, h->slot[0].d_out, h->slot[1].d_out,
-                    h->d_fold, h->d_mag, h->d_stats, h->d_xsel, h->d_rsel, h->d_partial_g, h->d_rec};
+                    h->d_fold, h->d_mag, h->d_stats, h->d_xsel, h->d_rsel, h->d_partial_g,
+                    h->slot[0].d_rec, h->slot[1].d_rec};
     for (void* p : olds)
         if (p) GPSMI_HIP(hipFree(p));
     h->d_tab_in = h->d_tab_out = nullptr; h->d_forced = nullptr;
-    for (auto& sl : h->slot) { sl.d_mid = nullptr; sl.d_partial = nullptr; sl.d_out = nullptr; }
+    for (auto& sl : h->slot) { sl.d_mid = nullptr; sl.d_partial = nullptr; sl.d_out = nullptr; sl.d_rec = nullptr; }
     h->njobs_cap = 0;
     h->d_fold = nullptr; h->d_mag = nullptr; h->d_stats = nullptr; h->d_xsel = h->d_rsel = nullptr;
-    h->d_partial_g = nullptr; h->d_rec = nullptr;
-    if (h->mfma == 4) {     // 32 records per (block, channel group) of the single-block span form
-        const size_t ng = (h->max_ch + kSpCh - 1) / kSpCh;
-        (void)ng;
-        GPSMI_HIP(hipMalloc((void**)&h->d_rec, (size_t)kSpanUnitsMax * 32 * kSpRecFloats * sizeof(float)));
-    }
+    h->d_partial_g = nullptr;
+    if (h->mfma == 4)       // 32 records per (block, channel group) of the single-block span form
+        for (auto& sl : h->slot)
+            GPSMI_HIP(hipMalloc((void**)&sl.d_rec, (size_t)kSpanUnitsMax * 32 * kSpRecFloats * sizeof(float)));
     if (h->general) {
         const size_t cs = h->cfg.code_samples;
         GPSMI_HIP(hipMalloc((void**)&h->d_fold, njobs * cs * sizeof(float2)));
-        GPSMI_HIP(hipMalloc((void**)&h->d_mag, njobs * cs * sizeof(float)));
+        if (!h->pfa) GPSMI_HIP(hipMalloc((void**)&h->d_mag, njobs * cs * sizeof(float)));
         GPSMI_HIP(hipMalloc((void**)&h->d_stats, njobs * sizeof(DirStats)));
         GPSMI_HIP(hipMalloc((void**)&h->d_xsel, njobs * sizeof(int)));
         GPSMI_HIP(hipMalloc((void**)&h->d_rsel, njobs * sizeof(int)));
@@ -465,7 +469,9 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
         hipLaunchKernelGGL(trk_fold_general_kernel, dim3((cs + 255) / 256, nblocks), dim3(256), 0,
                            h->stream, d_iq, h->d_t32, st_in, P, h->d_fold, h->d_xsel, h->d_rsel,
                            sl.d_mid);
-        if (h->big)
+        if (h->pfa)              // transform, product, transform and statistics in one launch
+            pfa_corr_launch(h->stream, h->d_fold, h->d_xsel, h->d_rsel, njobs, h->d_RSp, h->d_stats);
+        else if (h->big)
             big_corr_launch(h->stream, h->d_fold, h->d_xsel, h->d_rsel, njobs, cs, h->d_RS, h->d_S,
                             h->d_tw, h->d_twN, h->d_mag);
         else
@@ -473,8 +479,9 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
                                dim3((cs + kDirLagsPerWg - 1) / kDirLagsPerWg, njobs), dim3(256), 0,
                                h->stream, h->d_fold, h->d_code, h->d_xsel, h->d_rsel, cs,
                                h->d_mag);
-        hipLaunchKernelGGL(corr_stats_kernel, dim3(njobs), dim3(256), 0, h->stream, h->d_mag, cs,
-                           h->d_stats);
+        if (!h->pfa)
+            hipLaunchKernelGGL(corr_stats_kernel, dim3(njobs), dim3(256), 0, h->stream, h->d_mag, cs,
+                               h->d_stats);
         hipLaunchKernelGGL(trk_decide_kernel, dim3((njobs + 255) / 256), dim3(256), 0, h->stream,
                            h->d_stats, forced, P, njobs, sl.d_out, sl.d_mid);
     } else {
@@ -517,24 +524,24 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
         const dim3 mgrid(((nblocks + 7) / 8) * 8 * ng12);
         if (h->mfma == 4 && span_single && u8)
             hipLaunchKernelGGL((trk_span_kernel<1, 1, 0, 1>), dim3(nblocks * ng12 * 32), dim3(64), 0, h->stream,
-                               d_iq_v, sl.d_mid, h->d_code_eo, P, ng12, nblocks, h->d_rec, sl.d_partial);
+                               d_iq_v, sl.d_mid, h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
         else if (h->mfma == 4 && span_single)
             hipLaunchKernelGGL((trk_span_kernel<1, 1, 0, 0>), dim3(nblocks * ng12 * 32), dim3(64), 0, h->stream,
-                               d_iq_v, sl.d_mid, h->d_code_eo, P, ng12, nblocks, h->d_rec, sl.d_partial);
+                               d_iq_v, sl.d_mid, h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
         else if (h->mfma == 4 && ext_timed && (P.flags & 16)) {   // diagnostics: the timed launch is a second one
             hipLaunchKernelGGL((trk_span_kernel<8, 4, 0, 0>), span_grid, dim3(256), 0, h->stream,
-                               d_iq_v, sl.d_mid, h->d_code_eo, P, ng12, nblocks, h->d_rec, sl.d_partial);
+                               d_iq_v, sl.d_mid, h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
             hipExtLaunchKernelGGL((trk_span_kernel<8, 4, 0, 0>), span_grid, dim3(256), 0, h->stream,
                                   sl.ev[1], sl.ev[2], 0, d_iq_v, (const JobMid*)sl.d_mid,
-                                  (const float*)h->d_code_eo, P, ng12, nblocks, h->d_rec, sl.d_partial);
+                                  (const float*)h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
         } else if (h->mfma == 4 && ext_timed && u8)
             hipExtLaunchKernelGGL((trk_span_kernel<8, 4, 0, 1>), span_grid, dim3(256), 0, h->stream,
                                   sl.ev[1], sl.ev[2], 0, d_iq_v, (const JobMid*)sl.d_mid,
-                                  (const float*)h->d_code_eo, P, ng12, nblocks, h->d_rec, sl.d_partial);
+                                  (const float*)h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
         else if (h->mfma == 4 && ext_timed)
             hipExtLaunchKernelGGL((trk_span_kernel<8, 4, 0, 0>), span_grid, dim3(256), 0, h->stream,
                                   sl.ev[1], sl.ev[2], 0, d_iq_v, (const JobMid*)sl.d_mid,
-                                  (const float*)h->d_code_eo, P, ng12, nblocks, h->d_rec, sl.d_partial);
+                                  (const float*)h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
         else if (h->mfma == 4 && side_epilogue && h->done_by_dispatch) {
             // replay: the event the epilogue stream (and a search) waits for is the completion
             // signal of this very dispatch, not a record behind it - a record is one more
@@ -542,18 +549,18 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
             if (u8)
                 hipExtLaunchKernelGGL((trk_span_kernel<8, 4, 0, 1>), span_grid, dim3(256), 0, h->stream,
                                       nullptr, sl.corr_done, 0, d_iq_v, (const JobMid*)sl.d_mid,
-                                      (const float*)h->d_code_eo, P, ng12, nblocks, h->d_rec, sl.d_partial);
+                                      (const float*)h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
             else
                 hipExtLaunchKernelGGL((trk_span_kernel<8, 4, 0, 0>), span_grid, dim3(256), 0, h->stream,
                                       nullptr, sl.corr_done, 0, d_iq_v, (const JobMid*)sl.d_mid,
-                                      (const float*)h->d_code_eo, P, ng12, nblocks, h->d_rec, sl.d_partial);
+                                      (const float*)h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
             corr_done_recorded = true;
         } else if (h->mfma == 4 && u8)
             hipLaunchKernelGGL((trk_span_kernel<8, 4, 0, 1>), span_grid, dim3(256), 0, h->stream,
-                               d_iq_v, sl.d_mid, h->d_code_eo, P, ng12, nblocks, h->d_rec, sl.d_partial);
+                               d_iq_v, sl.d_mid, h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
         else if (h->mfma == 4)
             hipLaunchKernelGGL((trk_span_kernel<8, 4, 0, 0>), span_grid, dim3(256), 0, h->stream,
-                               d_iq_v, sl.d_mid, h->d_code_eo, P, ng12, nblocks, h->d_rec, sl.d_partial);
+                               d_iq_v, sl.d_mid, h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
         else if (h->mfma != 1)
             hipLaunchKernelGGL(trk_stream_mfma_kernel<4>, mgrid, dim3(256), 0, h->stream, d_iq,
                                sl.d_mid, h->d_code2, P, ng12, nblocks, sl.d_partial);
@@ -600,7 +607,7 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
     }
     if (span_single)
         hipLaunchKernelGGL(trk_epilogue_span_kernel, dim3(njobs), dim3(256), 0, es, st_in, st_out,
-                           sl.d_mid, h->d_rec, ng_span, P, njobs, sl.d_out);
+                           sl.d_mid, sl.d_rec, ng_span, P, njobs, sl.d_out);
     else
         hipLaunchKernelGGL(trk_epilogue_kernel, dim3((njobs + 3) / 4), dim3(256), 0, es, st_in,
                            st_out, sl.d_mid, sl.d_partial, P, njobs, sl.d_out);
@@ -645,6 +652,7 @@ static int trk_settle(gpsmi_trk* h) {
 
 static int trk_push_state(gpsmi_trk* h) {
     if (!h->state_dirty_host) return GPSMI_OK;
+    h->main_tail = nullptr;              // (new work on `stream`: the recorded tail no longer covers it)
     GPSMI_HIP(hipMemcpyAsync(h->d_state, h->h_state.data(), h->max_ch * sizeof(gpsmi_trk_state),
                              hipMemcpyHostToDevice, h->stream));
     GPSMI_HIP(hipStreamSynchronize(h->stream));
@@ -741,8 +749,15 @@ static int trk_build(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk* h) {
         }
     }
     if (h->general) {
-        const char* force = getenv("GPSMI_DIRECT_CORR");     // 1: keep the time-domain kernel
-        h->big = 2 * cfg->code_samples - 1 <= kBigN && !(force && atoi(force) == 1);
+        const char* force = getenv("GPSMI_DIRECT_CORR");     // 1: keep the time-domain kernel,
+        const int forced = force ? atoi(force) : 0;          // 2: the zero-padded 32768-point pair
+        h->pfa = cfg->code_samples == kPfaL && forced == 0;
+        h->big = !h->pfa && 2 * cfg->code_samples - 1 <= kBigN && forced != 1;
+    }
+    if (h->pfa) {
+        const size_t b = (size_t)(GPSMI_MAX_PRN + 1) * kPfaL * sizeof(float2);
+        GPSMI_HIP(hipMalloc((void**)&h->d_RSp, b));
+        GPSMI_HIP(hipMemset(h->d_RSp, 0, b));                // slot 0: closed channels
     }
     if (h->big) {
         std::vector<float2> twn(kBigN);
@@ -789,7 +804,7 @@ int gpsmi_trk_destroy(gpsmi_trk* h) {
                     h->slot[1].d_partial, h->slot[0].d_out,
                     h->slot[1].d_out, h->d_fold,
                     h->d_mag, h->d_stats, h->d_xsel, h->d_rsel, h->d_partial_g, h->d_twN, h->d_RS,
-                    h->d_S, h->d_code2, h->d_code_eo, h->d_rec};
+                    h->d_S, h->d_code2, h->d_code_eo, h->slot[0].d_rec, h->slot[1].d_rec, h->d_RSp};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto& sl : h->slot) {
@@ -829,8 +844,9 @@ int gpsmi_trk_set_replica(gpsmi_trk* h, int prn, const float* replica, const flo
     if (!h->general)                       // the other path needs no 2048-point spectrum
         GPSMI_HIP(hipMemcpy(h->d_rep + (size_t)prn * kFftN, spectrum, kFftN * sizeof(float2),
                             hipMemcpyHostToDevice));
-    if (h->big) {
-        big_replica_launch(h->stream, h->d_code, prn, (int)cs, h->d_RS, h->d_tw, h->d_twN);
+    if (h->big) big_replica_launch(h->stream, h->d_code, prn, (int)cs, h->d_RS, h->d_tw, h->d_twN);
+    if (h->pfa) pfa_replica_launch(h->stream, h->d_code, prn, h->d_RSp);
+    if (h->big || h->pfa) {
         GPSMI_HIP(hipGetLastError());
         GPSMI_HIP(hipStreamSynchronize(h->stream));
     }
@@ -942,6 +958,7 @@ int gpsmi_trk_process(gpsmi_trk* h, const float* iq, size_t n, gpsmi_trk_out* ou
     GPSMI_REQUIRE(h && iq && out, "null argument");
     GPSMI_REQUIRE(n == (size_t)h->cfg.n_cyc * h->cfg.code_samples, "block must hold NGPS samples");
     GPSMI_HIP(hipSetDevice(h->cfg.device));
+    h->main_tail = nullptr;
     GPSMI_HIP(hipMemcpyAsync(h->d_block, iq, n * (h->iq_fmt == GPSMI_IQ_U8 ? 2 : sizeof(float2)),
                              hipMemcpyHostToDevice, h->stream));
     return gpsmi_trk_process_dev(h, h->d_block, n, out);
@@ -964,8 +981,17 @@ int gpsmi_trk_replay_load(gpsmi_trk* h, int nb, const gpsmi_trk_state* table,
         if (delay_used && delay_used[j] >= h->cfg.code_samples)
             return fail(GPSMI_E_ARG, "replay table row %zu: delay_used out of range", j);
     }
-    int rc = trk_reserve(h, njobs);
+    // the epilogue of a run in flight reads d_tab_in and writes d_tab_out on its own stream: a new
+    // table may only land once every outstanding run has finished (gpsmi.h states the rule)
+    int rc = GPSMI_OK;
+    if (h->slot[0].epi_pending || h->slot[1].epi_pending || h->slot[0].copy_pending ||
+        h->slot[1].copy_pending) {
+        rc = trk_settle(h);
+        if (rc) return rc;
+    }
+    rc = trk_reserve(h, njobs);
     if (rc) return rc;
+    h->main_tail = nullptr;
     GPSMI_HIP(hipMemcpyAsync(h->d_tab_in, table, njobs * sizeof(gpsmi_trk_state),
                              hipMemcpyHostToDevice, h->stream));
     if (delay_used)

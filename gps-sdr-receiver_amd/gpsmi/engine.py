@@ -271,8 +271,12 @@ class TrkEngine:
                                                  ptr(out)),
                   'gpsmi_trk_process_dev')
         else:
-            iq = np.ascontiguousarray(iq, dtype=np.uint16 if getattr(self, 'raw_u8', False)
-                                      else np.complex64)
+            want = np.uint16 if getattr(self, 'raw_u8', False) else np.complex64
+            iq = np.asarray(iq)
+            if iq.dtype != want:       # a silent cast would turn one format into garbage of the other
+                raise TypeError(f'block dtype {iq.dtype} does not match the input format '
+                                f'({np.dtype(want).name}; see set_input_format)')
+            iq = np.ascontiguousarray(iq)
             if out is None:
                 out = np.zeros(self.max_ch, dtype=OUT_DTYPE)
             check(self.lib.gpsmi_trk_process(self.h, ptr(iq), iq.size, ptr(out)),

@@ -254,7 +254,9 @@ int gpsmi_trk_replay_fetch(gpsmi_trk* h, gpsmi_trk_out* out, size_t n);
  * run k: run_async, fetch_async(out_k), wait_prev (= run k-1 and its copy are
  * done, gpsmi_trk_last_ms reports run k-1), ... , wait (everything is done).  out
  * must be page-locked and stay valid until the wait that covers it; at most two
- * runs may be outstanding.                                                     */
+ * runs may be outstanding.  The state table is shared by the runs in flight:
+ * gpsmi_trk_replay_load first waits for every outstanding run (and its read-back),
+ * so load(k+1) after run_async(k) is safe, and costs that wait.                 */
 int gpsmi_trk_replay_run_async(gpsmi_trk* h, const void* d_iq, int nb);
 int gpsmi_trk_replay_fetch_async(gpsmi_trk* h, gpsmi_trk_out* out, size_t n);
 int gpsmi_trk_wait(gpsmi_trk* h);

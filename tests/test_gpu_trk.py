@@ -316,6 +316,58 @@ def test_pipelined_replay_runs_and_readbacks(closed_loop):
     assert all(g == outs.tobytes() for g in got)
 
 
+@pytest.mark.parametrize('done_by_dispatch', ['1', '0'])
+@pytest.mark.parametrize('nb', [8, 24])
+def test_async_batches_with_different_input_do_not_share_buffers(closed_loop, monkeypatch, nb,
+                                                                 done_by_dispatch):
+    """Consecutive asynchronous batches on DIFFERENT IQ (same state table): a dropped
+    cross-stream dependency or a scratch buffer shared by the two result slots returns the
+    other batch's sums.  nb = 8 takes the single-block form of the span correlator (raw
+    span records + its own epilogue), nb = 24 the batch form; GPSMI_DONE_BY_DISPATCH=0 swaps
+    the dispatch's completion signal for an event record.  Every read-back must equal the
+    blocking replay of the same input on a fresh handle."""
+    from gpsmi.engine import TrkEngine, DeviceBuffer, PinnedArray, OUT_DTYPE
+    _, outs, states, blocks = closed_loop
+    nch = outs.shape[1]
+    bufs = []
+    for first in (0, nb):                      # two different stretches of the recording
+        buf = DeviceBuffer(nb * blocks[0].nbytes)
+        for i in range(nb):
+            buf.upload(blocks[first + i], i * blocks[0].nbytes)
+        bufs.append(buf)
+    table, forced = states[:nb], outs['delay_used'][:nb]
+    ref_eng = TrkEngine(max_ch=nch)
+    want = [ref_eng.replay(b.ptr, nb, table, forced).tobytes() for b in bufs]
+    ref_eng.close()
+    assert want[0] != want[1]
+    monkeypatch.setenv('GPSMI_DONE_BY_DISPATCH', done_by_dispatch)
+    eng = TrkEngine(max_ch=nch)
+    monkeypatch.delenv('GPSMI_DONE_BY_DISPATCH')
+    eng.replay_load(nb, table, forced)
+    pins = [PinnedArray((nb, nch), OUT_DTYPE) for _ in range(2)]
+    order = [0, 1, 1, 0, 1, 0, 0]
+    for k, which in enumerate(order):
+        pins[k & 1].array.view(np.uint8)[:] = 0xAB
+        eng.set_timing(k % 3 == 0)
+        eng.replay_run_async(bufs[which].ptr, nb)
+        eng.replay_fetch_async(pins[k & 1].array)
+        eng.wait_prev()
+        if k > 0:
+            assert pins[(k - 1) & 1].array.tobytes() == want[order[k - 1]], (k - 1, nb)
+    eng.wait()
+    assert pins[(len(order) - 1) & 1].array.tobytes() == want[order[-1]]
+    # a new table while a run is in flight: replay_load waits for it (gpsmi.h)
+    eng.replay_run_async(bufs[0].ptr, nb)
+    eng.replay_fetch_async(pins[0].array)
+    eng.replay_load(nb, table, forced)
+    assert pins[0].array.tobytes() == want[0]
+    eng.close()
+    for b in bufs:
+        b.free()
+    for p_ in pins:
+        p_.free()
+
+
 def test_search_ordered_behind_replay_batches(closed_loop):
     """The step of bench.py: a search on its own handle ordered on the device behind the
     previous batch's correlator (gpsmi_acq_after_trk: the dispatch's own completion event),
