@@ -258,6 +258,37 @@ def measure_cfg5(E, local, iters=8):
             'x_realtime': round(nb * ngps / t / 1e3 / 16.368, 1)}
 
 
+def measure_batched(E, local, iq_at, nb_avail, chans, Rs=(1, 8, 32, 64), max_steps=64):
+    """the closed loop of R independent receivers on one handle
+    (gpsmi_trk_set_streams), state fed back on the device block by block, nothing read back
+    and no host wait inside the loop.  Slab s of the resident buffer holds block s of every
+    stream (R blocks back to back); iq_at(block) -> device pointer."""
+    res = []
+    for R in Rs:
+        steps = min(max_steps, nb_avail // R)
+        if steps < 2:
+            continue
+        trk = E.TrkEngine(E.Config(device=local), max_ch=max(1, len(chans)), streams=R)
+        for r in range(R):
+            for c, (s, f, d) in enumerate(chans):
+                trk.open(c, s, f, d, stream=r)
+        trk.set_timing(False)
+        best = None
+        for rep in range(3):                       # (the first pass also uploads the state rows)
+            E.sync(local)
+            t0 = time.perf_counter()
+            for i in range(steps):
+                trk.process(iq_at(i * R), want_out=False)
+            E.sync(local)
+            t = (time.perf_counter() - t0) / steps
+            best = t if best is None else min(best, t)
+        trk.close()
+        res.append({'R': R, 'channels': R * len(chans), 'us_per_step': round(best * 1e6, 2),
+                    'msamples_per_s': round(R * NGPS / best / 1e6, 1),
+                    'x_realtime_per_stream': round(NGPS / best / 2.048e6, 1)})
+    return res
+
+
 # ---------------------------------------------------------------------- main
 def main():
     # stdout carries exactly one JSON line: whatever libraries print there while we run
@@ -374,6 +405,8 @@ def main():
     E.sync(local)
     t_closed = time.perf_counter() - t0
     trk.set_timing(True)
+    batched = measure_batched(E, local, lambda b: d_iq.at(trk_base + b * blk_bytes), nb, chans) \
+        if rank == 0 and not a.no_extra else []
 
     # the acquisition leg of a step: configs[1] on one GPU, configs[3] sharded by SV on N
     prn_all = list(range(1, 33))
@@ -612,6 +645,9 @@ def main():
                 'with_per_block_readback_msps':
                     round(samples / t_closed_with_readback / 1e6, 1),
                 'device_ms_per_block': round(cl_dev_ms / nb, 4),
+                'batched': batched,
+                'batched_note': 'R independent receivers per handle (gpsmi_trk_set_streams), each '
+                                'bytewise equal to its solo closed loop (tests/test_gpu_trk.py)',
             },
             'configs': extra,
             'checks': checks,

@@ -17,7 +17,7 @@
 //       samples that share (n mod 3, n mod 11, n mod 31).  Their Z_16 coordinate is
 //       (c - j) mod 16, so a plain FFT-16 over j followed by exp(+2 pi i c k / 16) is the
 //       DFT along that axis; the 16 results go to LDS[k][sigma(c)],
-//       sigma(c) = ((c mod 3) 11 + c mod 11) 31 + c mod 31.
+//       sigma(c) = (c mod 3) 352 + (c mod 11) 32 + c mod 31 (the LDS image, see kPfaPitch).
 //   P2  496 threads, one (k, i31) each: DFT-3 x DFT-11 over the 33 elements at stride 31.
 //   P3  528 threads, one (k, i3, i11) each: DFT-31 of 31 contiguous elements, times the
 //       replica spectrum (conjugated: the way back runs as a forward transform of the
@@ -42,7 +42,14 @@ namespace gpsmi {
 
 constexpr int kPfaL = 16368;
 constexpr int kPfaC = 1023;          // 3 * 11 * 31
-constexpr int kPfaPitch = 1024;      // complex elements per Z_16 row in LDS
+// LDS image: element (k, i3, i11, i31) at k * kPfaPitch + i3 * kPfaS3 + i11 * kPfaS11 + i31.  The strides
+// of i3 and i11 are multiples of 32 and the pitch is 31 mod 32, so that the bank of an element is
+// (i31 - k) mod 32: the scatter of P1 / gather of P5 (64 consecutive c per wave: i31 runs, i3 and i11
+// wrap) meets one repeated bank per 32 lanes instead of the eight of the dense order, P2 / P4 (lanes
+// along i31) are conflict-free, and P3's lanes run along k first (tools: a search over the padded
+// mixed-radix orders).
+constexpr int kPfaS11 = 32, kPfaS3 = 11 * 32;
+constexpr int kPfaPitch = 1087;      // complex elements per Z_16 row in LDS (>= 3 * kPfaS3 = 1056)
 constexpr int kPfaThreads = 1024;
 constexpr int kPfaLines31 = 528;     // 16 * 33 lines along Z_31
 constexpr int kPfaSlabs33 = 496;     // 16 * 31 slabs Z_3 x Z_11
@@ -143,16 +150,25 @@ __device__ __forceinline__ void pfa_dft_prime(fft_c* x, Pre pre, Out0 out0, Out 
     }
 }
 
+// probe builds only (tools/probe/pfa_prof.hip): the shader clock at the phase boundaries of
+// every workgroup, into a buffer nothing else reads
+#ifdef GPSMI_PFA_STAMPS
+__device__ unsigned long long* g_pfa_stamps;
+#define PFA_STAMP(i) do { if (t == 0) g_pfa_stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PFA_STAMP(i) do {} while (0)
+#endif
+
 struct PfaNoPre { __device__ __forceinline__ void operator()(int) const {} };
 
 // sigma(c): position of the Z_1023 element c inside a row
-__device__ __forceinline__ int pfa_sigma(int c) { return ((c % 3) * 11 + c % 11) * 31 + c % 31; }
+__device__ __forceinline__ int pfa_sigma(int c) { return (c % 3) * kPfaS3 + (c % 11) * kPfaS11 + c % 31; }
 
-// DFT-3 x DFT-11 in place over the 33 elements base[(i3 * 11 + i11) * 31]
+// DFT-3 x DFT-11 in place over the 33 elements base[i3 * kPfaS3 + i11 * kPfaS11]
 __device__ __forceinline__ void pfa_slab33(fft_c* base) {
     fft_c v[33];
 #pragma unroll
-    for (int i = 0; i < 33; ++i) v[i] = base[i * 31];
+    for (int i = 0; i < 33; ++i) v[i] = base[(i / 11) * kPfaS3 + (i % 11) * kPfaS11];
     // Z_3 first, in registers: three elements i11 apart by 11
 #pragma unroll
     for (int i11 = 0; i11 < 11; ++i11) {
@@ -164,10 +180,10 @@ __device__ __forceinline__ void pfa_slab33(fft_c* base) {
     // Z_11, results straight to LDS
 #pragma unroll
     for (int i3 = 0; i3 < 3; ++i3) {
-        fft_c* col = base + i3 * 11 * 31;
+        fft_c* col = base + i3 * kPfaS3;
         pfa_dft_prime<11>(
             v + i3 * 11, PfaNoPre{}, [&](fft_c X0) { col[0] = X0; },
-            [&](int k, fft_c Xk, fft_c Xpk) { col[k * 31] = Xk; col[(11 - k) * 31] = Xpk; });
+            [&](int k, fft_c Xk, fft_c Xpk) { col[k * kPfaS11] = Xk; col[(11 - k) * kPfaS11] = Xpk; });
     }
 }
 
@@ -188,6 +204,7 @@ __global__ __launch_bounds__(kPfaThreads) void pfa_corr_kernel(
     __shared__ fft_c tw16[16];                    // exp(+2 pi i m / 16)
     if (t < 16) tw16[t] = pfa_w16(t, false);
     __syncthreads();
+    PFA_STAMP(0);
 
     // ---- P1: load, FFT-16 along Z_16, coordinate twiddle, scatter to LDS
     if (t < kPfaC) {
@@ -210,14 +227,16 @@ __global__ __launch_bounds__(kPfaThreads) void pfa_corr_kernel(
         for (int k = 1; k < 16; ++k) data[k * kPfaPitch + sig] = cmulp(v[k], tw16[(t * k) & 15]);
     }
     __syncthreads();
+    PFA_STAMP(1);
 
     // ---- P2: Z_3 x Z_11
     if (t < kPfaSlabs33) pfa_slab33(data + (t / 31) * kPfaPitch + (t % 31));
     __syncthreads();
+    PFA_STAMP(2);
 
     // ---- P3: Z_31, x conj(replica spectrum), Z_31 again
     if (t < kPfaLines31) {
-        fft_c* line = data + (t / 33) * kPfaPitch + (t % 33) * 31;
+        fft_c* line = data + (t % 16) * kPfaPitch + ((t / 16) % 3) * kPfaS3 + (t / 48) * kPfaS11;
         fft_c v[31];
 #pragma unroll
         for (int i = 0; i < 31; ++i) v[i] = line[i];
@@ -260,10 +279,12 @@ __global__ __launch_bounds__(kPfaThreads) void pfa_corr_kernel(
     }
     if (MODE == 1) return;
     __syncthreads();
+    PFA_STAMP(3);
 
     // ---- P4: Z_3 x Z_11 on the way back
     if (t < kPfaSlabs33) pfa_slab33(data + (t / 31) * kPfaPitch + (t % 31));
     __syncthreads();
+    PFA_STAMP(4);
 
     // ---- P5: coordinate twiddle, FFT-16, magnitudes at lag n = t + 1023 j, statistics
     float mag[16];
@@ -285,6 +306,7 @@ __global__ __launch_bounds__(kPfaThreads) void pfa_corr_kernel(
 #pragma unroll
         for (int j = 0; j < 16; ++j) mag[j] = 0.f;
     }
+    PFA_STAMP(5);
     sm = wave_sum_dpp(sm);
     wave_argmax_dpp(bv, bi);
     if (lane == 0) { red_s[wave] = sm; red_v[wave] = bv; red_i[wave] = bi; }
@@ -333,6 +355,7 @@ __global__ __launch_bounds__(kPfaThreads) void pfa_corr_kernel(
         r.hi = nbr[1];
         out[cell] = r;
     }
+    PFA_STAMP(6);
 }
 
 // all correlations of `ncell` cells on `stream`, statistics included

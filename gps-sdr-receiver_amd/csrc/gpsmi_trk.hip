@@ -342,6 +342,12 @@ using namespace gpsmi;
 struct gpsmi_trk {
     gpsmi_cfg cfg;
     int max_ch = 0;
+    int n_streams = 1;                   // independent receivers (IQ streams) of the closed loop; a state
+                                         // row is stream * max_ch + channel
+    int rows() const { return n_streams * max_ch; }
+    int span_single_max = 96;            // (block, channel group) units up to which the span correlator runs
+                                         // its single-block form (GPSMI_SPAN_SINGLE_MAX; measured: 51 against 56 us
+                                         // per step at 64 units, 79 against 67 at 128)
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;   // result read-back, overlaps the next replay run
     hipStream_t epi_stream = nullptr;    // replay: the epilogue of run k beside the code-phase
@@ -404,7 +410,7 @@ struct gpsmi_trk {
     TrkParams P;
 };
 
-constexpr int kSpanUnitsMax = 16;    // (block, channel group) pairs the single-block span form serves
+constexpr int kSpanUnitsMax = 256;   // (block, channel group) units the single-block span form can serve (records)
 
 static int trk_reserve(gpsmi_trk* h, size_t njobs) {
     if (njobs <= h->njobs_cap) return GPSMI_OK;
@@ -462,7 +468,7 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
     // a launch too small to fill the CUs with whole blocks (the closed loop): every span of
     // a block is a wave of its own; same bits as the batch form (gpsmi_trk_span.h)
     const int ng_span = (nch + kSpCh - 1) / kSpCh;
-    const bool span_single = h->mfma == 4 && nblocks * ng_span <= kSpanUnitsMax;
+    const bool span_single = h->mfma == 4 && nblocks * ng_span <= h->span_single_max;
     // ---- code-phase correlation
     if (h->general) {
         const int cs = P.cs;
@@ -653,7 +659,7 @@ static int trk_settle(gpsmi_trk* h) {
 static int trk_push_state(gpsmi_trk* h) {
     if (!h->state_dirty_host) return GPSMI_OK;
     h->main_tail = nullptr;              // (new work on `stream`: the recorded tail no longer covers it)
-    GPSMI_HIP(hipMemcpyAsync(h->d_state, h->h_state.data(), h->max_ch * sizeof(gpsmi_trk_state),
+    GPSMI_HIP(hipMemcpyAsync(h->d_state, h->h_state.data(), h->rows() * sizeof(gpsmi_trk_state),
                              hipMemcpyHostToDevice, h->stream));
     GPSMI_HIP(hipStreamSynchronize(h->stream));
     h->state_dirty_host = false;
@@ -662,7 +668,7 @@ static int trk_push_state(gpsmi_trk* h) {
 
 static int trk_pull_state(gpsmi_trk* h) {
     if (h->state_dirty_host) return GPSMI_OK;        // host copy is the newest
-    GPSMI_HIP(hipMemcpyAsync(h->h_state.data(), h->d_state, h->max_ch * sizeof(gpsmi_trk_state),
+    GPSMI_HIP(hipMemcpyAsync(h->h_state.data(), h->d_state, h->rows() * sizeof(gpsmi_trk_state),
                              hipMemcpyDeviceToHost, h->stream));
     GPSMI_HIP(hipStreamSynchronize(h->stream));
     return GPSMI_OK;
@@ -788,6 +794,10 @@ static int trk_build(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk* h) {
     const char* cgs = getenv("GPSMI_CORR_CG");
     if (cgs && (atoi(cgs) == 2 || atoi(cgs) == 4 || atoi(cgs) == 6)) h->corr_cg = atoi(cgs);
     if (const char* dd = getenv("GPSMI_DONE_BY_DISPATCH")) h->done_by_dispatch = atoi(dd) != 0;
+    if (const char* sm = getenv("GPSMI_SPAN_SINGLE_MAX")) {
+        const int v = atoi(sm);
+        if (v >= 1 && v <= kSpanUnitsMax) h->span_single_max = v;
+    }
     return trk_reserve(h, max_ch);
 }
 
@@ -856,7 +866,7 @@ int gpsmi_trk_set_replica(gpsmi_trk* h, int prn, const float* replica, const flo
 
 int gpsmi_trk_open(gpsmi_trk* h, int ch, int prn, float freq_hz, int delay) {
     GPSMI_REQUIRE(h, "null handle");
-    GPSMI_REQUIRE(ch >= 0 && ch < h->max_ch, "channel out of range");
+    GPSMI_REQUIRE(ch >= 0 && ch < h->rows(), "channel out of range");
     GPSMI_REQUIRE(prn >= 1 && prn <= GPSMI_MAX_PRN, "prn out of range 1..37");
     GPSMI_REQUIRE(delay >= 0 && delay < h->cfg.code_samples, "delay out of range");
     if (!h->have_rep[prn]) return fail(GPSMI_E_STATE, "no replica set for PRN %d", prn);
@@ -874,7 +884,7 @@ int gpsmi_trk_open(gpsmi_trk* h, int ch, int prn, float freq_hz, int delay) {
 
 int gpsmi_trk_close(gpsmi_trk* h, int ch) {
     GPSMI_REQUIRE(h, "null handle");
-    GPSMI_REQUIRE(ch >= 0 && ch < h->max_ch, "channel out of range");
+    GPSMI_REQUIRE(ch >= 0 && ch < h->rows(), "channel out of range");
     GPSMI_HIP(hipSetDevice(h->cfg.device));
     int rc = trk_pull_state(h);
     if (rc) return rc;
@@ -886,7 +896,7 @@ int gpsmi_trk_close(gpsmi_trk* h, int ch) {
 
 int gpsmi_trk_get_state(gpsmi_trk* h, int ch, gpsmi_trk_state* st) {
     GPSMI_REQUIRE(h && st, "null argument");
-    GPSMI_REQUIRE(ch >= 0 && ch < h->max_ch, "channel out of range");
+    GPSMI_REQUIRE(ch >= 0 && ch < h->rows(), "channel out of range");
     GPSMI_HIP(hipSetDevice(h->cfg.device));
     int rc = trk_pull_state(h);
     if (rc) return rc;
@@ -896,7 +906,7 @@ int gpsmi_trk_get_state(gpsmi_trk* h, int ch, gpsmi_trk_state* st) {
 
 int gpsmi_trk_set_state(gpsmi_trk* h, int ch, const gpsmi_trk_state* st) {
     GPSMI_REQUIRE(h && st, "null argument");
-    GPSMI_REQUIRE(ch >= 0 && ch < h->max_ch, "channel out of range");
+    GPSMI_REQUIRE(ch >= 0 && ch < h->rows(), "channel out of range");
     GPSMI_REQUIRE(st->prn >= 0 && st->prn <= GPSMI_MAX_PRN, "prn out of range");
     GPSMI_REQUIRE(st->delay >= 0 && st->delay < h->cfg.code_samples, "delay out of range");
     GPSMI_REQUIRE(st->nps >= 0 && st->nps <= h->cfg.code_samples, "nps out of range");
@@ -913,7 +923,7 @@ int gpsmi_trk_set_state(gpsmi_trk* h, int ch, const gpsmi_trk_state* st) {
 
 int gpsmi_trk_erase_prev(gpsmi_trk* h, int ch) {
     GPSMI_REQUIRE(h, "null handle");
-    GPSMI_REQUIRE(ch >= 0 && ch < h->max_ch, "channel out of range");
+    GPSMI_REQUIRE(ch >= 0 && ch < h->rows(), "channel out of range");
     GPSMI_HIP(hipSetDevice(h->cfg.device));
     int rc = trk_pull_state(h);
     if (rc) return rc;
@@ -925,7 +935,8 @@ int gpsmi_trk_erase_prev(gpsmi_trk* h, int ch) {
 
 int gpsmi_trk_process_dev(gpsmi_trk* h, const void* d_iq, size_t n, gpsmi_trk_out* out) {
     GPSMI_REQUIRE(h && d_iq, "null argument");
-    GPSMI_REQUIRE(n == (size_t)h->cfg.n_cyc * h->cfg.code_samples, "block must hold NGPS samples");
+    GPSMI_REQUIRE(n == (size_t)h->n_streams * h->cfg.n_cyc * h->cfg.code_samples,
+                  "input must hold one block of NGPS samples per stream");
     GPSMI_HIP(hipSetDevice(h->cfg.device));
     int rc = trk_push_state(h);
     if (rc) return rc;
@@ -937,11 +948,12 @@ int gpsmi_trk_process_dev(gpsmi_trk* h, const void* d_iq, size_t n, gpsmi_trk_ou
     }
     gpsmi_trk::Slot& sl = h->slot[0];      // the closed loop needs one slot only
     h->cur = 0;
-    rc = trk_launch(h, sl, d_iq, h->d_state, h->d_state, nullptr, h->max_ch,
-                    h->max_ch);
+    // the streams of a handle are the "blocks" of one launch: stream r reads block r of d_iq and
+    // owns the state rows r * max_ch ..., updated in place
+    rc = trk_launch(h, sl, d_iq, h->d_state, h->d_state, nullptr, h->rows(), h->max_ch);
     if (rc) return rc;
     if (out)
-        GPSMI_HIP(hipMemcpyAsync(out, sl.d_out, h->max_ch * sizeof(gpsmi_trk_out),
+        GPSMI_HIP(hipMemcpyAsync(out, sl.d_out, h->rows() * sizeof(gpsmi_trk_out),
                                  hipMemcpyDeviceToHost, h->stream));
     // nothing to hand back: the block is enqueued, the state stays on the device and the
     // next call queues behind it (get_state / wait / a call with `out` synchronise)
@@ -956,7 +968,8 @@ int gpsmi_trk_process_dev(gpsmi_trk* h, const void* d_iq, size_t n, gpsmi_trk_ou
 
 int gpsmi_trk_process(gpsmi_trk* h, const float* iq, size_t n, gpsmi_trk_out* out) {
     GPSMI_REQUIRE(h && iq && out, "null argument");
-    GPSMI_REQUIRE(n == (size_t)h->cfg.n_cyc * h->cfg.code_samples, "block must hold NGPS samples");
+    GPSMI_REQUIRE(n == (size_t)h->n_streams * h->cfg.n_cyc * h->cfg.code_samples,
+                  "input must hold one block of NGPS samples per stream");
     GPSMI_HIP(hipSetDevice(h->cfg.device));
     h->main_tail = nullptr;
     GPSMI_HIP(hipMemcpyAsync(h->d_block, iq, n * (h->iq_fmt == GPSMI_IQ_U8 ? 2 : sizeof(float2)),
@@ -968,6 +981,7 @@ int gpsmi_trk_replay_load(gpsmi_trk* h, int nb, const gpsmi_trk_state* table,
                           const int32_t* delay_used) {
     GPSMI_REQUIRE(h && table, "null argument");
     GPSMI_REQUIRE(nb >= 1, "block count must be >= 1");
+    if (h->n_streams != 1) return fail(GPSMI_E_STATE, "replay takes a handle with one stream");
     GPSMI_HIP(hipSetDevice(h->cfg.device));
     const int nch = h->max_ch;
     const size_t njobs = (size_t)nb * nch;
@@ -1123,6 +1137,31 @@ int gpsmi_trk_set_input_format(gpsmi_trk* h, int fmt) {
                                          "(the span correlator)");
     h->iq_fmt = fmt;
     return GPSMI_OK;
+}
+
+int gpsmi_trk_set_streams(gpsmi_trk* h, int n_streams) {
+    GPSMI_REQUIRE(h, "null handle");
+    GPSMI_REQUIRE(n_streams >= 1 && (long long)n_streams * h->max_ch <= 65536,
+                  "n_streams out of range (streams x channels <= 65536)");
+    GPSMI_HIP(hipSetDevice(h->cfg.device));
+    int rc = trk_settle(h);
+    if (rc) return rc;
+    const size_t rows = (size_t)n_streams * h->max_ch;
+    const size_t ngps = (size_t)h->cfg.n_cyc * h->cfg.code_samples;
+    if (h->d_state) GPSMI_HIP(hipFree(h->d_state));
+    h->d_state = nullptr;
+    if (h->d_block) GPSMI_HIP(hipFree(h->d_block));
+    h->d_block = nullptr;
+    h->n_streams = 1;                      // (a failure below leaves a consistent one-stream handle...
+    h->h_state.assign(h->max_ch, gpsmi_trk_state{});
+    h->state_dirty_host = false;
+    GPSMI_HIP(hipMalloc((void**)&h->d_state, rows * sizeof(gpsmi_trk_state)));   // ... whose buffers are at least this big)
+    GPSMI_HIP(hipMemset(h->d_state, 0, rows * sizeof(gpsmi_trk_state)));
+    GPSMI_HIP(hipMalloc((void**)&h->d_block, (size_t)n_streams * ngps * sizeof(float2)));
+    h->h_state.assign(rows, gpsmi_trk_state{});
+    h->n_streams = n_streams;
+    h->replay_nb = 0;
+    return trk_reserve(h, rows);
 }
 
 int gpsmi_trk_set_timing(gpsmi_trk* h, int on) {

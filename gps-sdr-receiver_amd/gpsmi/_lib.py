@@ -72,7 +72,7 @@ EXPORTS = [
     'gpsmi_trk_replay_run_async', 'gpsmi_trk_replay_fetch_async', 'gpsmi_trk_wait',
     'gpsmi_trk_wait_prev', 'gpsmi_trk_after_acq', 'gpsmi_acq_after_trk', 'gpsmi_trk_set_timing',
     'gpsmi_trk_last_ms',
-    'gpsmi_trk_set_input_format',
+    'gpsmi_trk_set_input_format', 'gpsmi_trk_set_streams',
     'gpsmi_comm_unique_id', 'gpsmi_comm_create', 'gpsmi_comm_destroy',
     'gpsmi_comm_allgather_peaks',
 ]

@@ -224,15 +224,21 @@ class TrkEngine:
     """All tracking channels of one GPU (numeric part of SatStream.process,
     reference gpslib.py:1141-1210)."""
 
-    def __init__(self, cfg=None, max_ch=12, prns=range(1, 38)):
+    def __init__(self, cfg=None, max_ch=12, prns=range(1, 38), streams=1):
+        """streams > 1: that many independent receivers (IQ streams) share the handle and
+        every launch (gpsmi_trk_set_streams); a channel is then addressed as (ch, stream)."""
         self.cfg = cfg or Config()
         self.max_ch = max_ch
+        self.streams = 1
         self.lib = _lib.load()
         h = C.c_void_p()
         cs = self.cfg.c_struct()
         check(self.lib.gpsmi_trk_create(C.byref(cs), max_ch, C.byref(h)),
               'gpsmi_trk_create')
         self.h = h
+        if streams != 1:
+            check(self.lib.gpsmi_trk_set_streams(self.h, int(streams)), 'gpsmi_trk_set_streams')
+            self.streams = int(streams)
         for p in prns:
             rep = np.ascontiguousarray(
                 codes.code_replica(p, self.cfg.code_samples).astype(np.float32))
@@ -240,34 +246,43 @@ class TrkEngine:
             check(self.lib.gpsmi_trk_set_replica(self.h, p, ptr(rep), ptr(spec)),
                   'gpsmi_trk_set_replica')
 
-    def open(self, ch, prn, freq, delay):
-        check(self.lib.gpsmi_trk_open(self.h, ch, prn, float(freq), int(delay)),
+    def _row(self, ch, stream):
+        if self.streams == 1 and stream == 0:
+            return ch                         # (the library checks the range itself)
+        if not (0 <= ch < self.max_ch and 0 <= stream < self.streams):
+            raise ValueError('channel / stream out of range')
+        return stream * self.max_ch + ch
+
+    def open(self, ch, prn, freq, delay, stream=0):
+        check(self.lib.gpsmi_trk_open(self.h, self._row(ch, stream), prn, float(freq), int(delay)),
               'gpsmi_trk_open')
 
-    def close_channel(self, ch):
-        check(self.lib.gpsmi_trk_close(self.h, ch), 'gpsmi_trk_close')
+    def close_channel(self, ch, stream=0):
+        check(self.lib.gpsmi_trk_close(self.h, self._row(ch, stream)), 'gpsmi_trk_close')
 
-    def get_state(self, ch):
+    def get_state(self, ch, stream=0):
         st = np.zeros(1, dtype=STATE_DTYPE)
-        check(self.lib.gpsmi_trk_get_state(self.h, ch, ptr(st)),
+        check(self.lib.gpsmi_trk_get_state(self.h, self._row(ch, stream), ptr(st)),
               'gpsmi_trk_get_state')
         return st[0]
 
-    def set_state(self, ch, st):
+    def set_state(self, ch, st, stream=0):
         a = np.zeros(1, dtype=STATE_DTYPE)
         a[0] = st
-        check(self.lib.gpsmi_trk_set_state(self.h, ch, ptr(a)),
+        check(self.lib.gpsmi_trk_set_state(self.h, self._row(ch, stream), ptr(a)),
               'gpsmi_trk_set_state')
 
-    def erase_prev(self, ch):
-        check(self.lib.gpsmi_trk_erase_prev(self.h, ch), 'gpsmi_trk_erase_prev')
+    def erase_prev(self, ch, stream=0):
+        check(self.lib.gpsmi_trk_erase_prev(self.h, self._row(ch, stream)), 'gpsmi_trk_erase_prev')
 
     def process(self, iq, want_out=True):
         """One closed-loop block for every open channel.  iq: complex64[NGPS]
-        on the host, or a c_void_p to a device-resident block."""
-        out = np.zeros(self.max_ch, dtype=OUT_DTYPE) if want_out else None
+        on the host, or a c_void_p to a device-resident block.  With streams > 1:
+        [streams, NGPS] (one block per stream, back to back); out is [streams, max_ch]."""
+        shape = self.max_ch if self.streams == 1 else (self.streams, self.max_ch)
+        out = np.zeros(shape, dtype=OUT_DTYPE) if want_out else None
         if isinstance(iq, C.c_void_p):
-            check(self.lib.gpsmi_trk_process_dev(self.h, iq, self.cfg.ngps,
+            check(self.lib.gpsmi_trk_process_dev(self.h, iq, self.streams * self.cfg.ngps,
                                                  ptr(out)),
                   'gpsmi_trk_process_dev')
         else:
@@ -278,7 +293,7 @@ class TrkEngine:
                                 f'({np.dtype(want).name}; see set_input_format)')
             iq = np.ascontiguousarray(iq)
             if out is None:
-                out = np.zeros(self.max_ch, dtype=OUT_DTYPE)
+                out = np.zeros(shape, dtype=OUT_DTYPE)
             check(self.lib.gpsmi_trk_process(self.h, ptr(iq), iq.size, ptr(out)),
                   'gpsmi_trk_process')
         return out

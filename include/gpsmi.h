@@ -219,6 +219,16 @@ int gpsmi_trk_process(gpsmi_trk* h, const float* iq, size_t n,
 int gpsmi_trk_process_dev(gpsmi_trk* h, const void* d_iq, size_t n,
                           gpsmi_trk_out* out);
 
+/* Batched receivers: R independent IQ streams (receivers) tracked by one handle, so that the
+ * closed loop -- a chain of three dependent launches per 32-ms block -- fills the GPU with the
+ * jobs of R x max_ch channels instead of max_ch.  After the call the handle has R * max_ch state
+ * rows, all closed; the channel index of open / close / get_state / set_state / erase_prev is
+ * stream * max_ch + ch, process / process_dev take R blocks back to back (n = R * NGPS; stream r
+ * reads block r) and write out[R * max_ch].  Every stream computes exactly what it computes alone
+ * on a handle of its own (SatStream.process, gpslib.py:1141-1210, once per stream and channel).
+ * Replay keeps to one stream.                                                          */
+int gpsmi_trk_set_streams(gpsmi_trk* h, int n_streams);
+
 /* Input format of the blocks that process / process_dev / replay* receive (default
  * GPSMI_IQ_C64).  GPSMI_IQ_U8: the raw recording format of streamData (gpsrecv.py:162-173),
  * uint16 (Q << 8 | I) per sample, 2 bytes instead of 8 over PCIe and from HBM; the kernels

@@ -676,3 +676,47 @@ def test_result_slots_carry_nothing_over(closed_loop):
     assert again.tobytes() == ref.tobytes()
     assert not np.frombuffer(again[:, 1].tobytes(), dtype=np.uint8).any()   # closed channel: zeros
     assert (again['prn'][:, 0] > 0).all()
+
+
+@pytest.mark.parametrize('R', [1, 8, 32])
+def test_batched_receivers_equal_their_solo_closed_loops(golden_default, R):
+    """gpsmi_trk_set_streams: R independent IQ streams tracked by one handle, all channels of
+    all streams in every launch trio.  Stream r must produce, byte for byte, the records and
+    the state of a closed loop that runs alone on a handle of its own."""
+    from gpsmi.engine import TrkEngine, DeviceBuffer, OUT_DTYPE
+    g = golden_default
+    nch, steps = 12, 6
+    blocks = scene_blocks('default', 5, R + steps)
+    # stream r = the recording from block r on: different samples, phases and delays per stream
+    solo = np.zeros((R, steps, nch), dtype=OUT_DTYPE)
+    solo_state = []
+    for r in range(R):
+        eng = TrkEngine(max_ch=nch)
+        _open_all(eng, g)
+        if r % 3 == 1:
+            eng.close_channel(r % nch)             # (a stream with a closed channel among the others)
+        for i in range(steps):
+            solo[r, i] = eng.process(blocks[r + i])
+        solo_state.append([eng.get_state(c).tobytes() for c in range(nch)])
+        eng.close()
+    eng = TrkEngine(max_ch=nch, streams=R)
+    for r in range(R):
+        for c, (sv, f0, d0) in enumerate(g['trk_init']):
+            eng.open(c, int(sv), float(f0), int(d0), stream=r)
+        if r % 3 == 1:
+            eng.close_channel(r % nch, stream=r)
+    buf = DeviceBuffer(R * blocks[0].nbytes)
+    for i in range(steps):
+        slab = np.stack([blocks[r + i] for r in range(R)])
+        if i % 2 == 0:                               # host input ...
+            out = eng.process(slab)
+        else:                                        # ... and device-resident input
+            buf.upload(slab)
+            out = eng.process(buf.ptr)
+        out = out.reshape(R, nch)
+        for r in range(R):
+            assert out[r].tobytes() == solo[r, i].tobytes(), (r, i)
+    for r in range(R):
+        assert [eng.get_state(c, stream=r).tobytes() for c in range(nch)] == solo_state[r], r
+    buf.free()
+    eng.close()
