@@ -33,9 +33,10 @@ namespace gpsmi {
 // searches): 1024 threads, the periods dealt round-robin to four groups of 256 whose partial
 // folds meet in LDS (the sine / cosine per sample is what this kernel spends its time on);
 // group 0 then adds them in group order and transforms.
-template <int G>
+// (FMT 1: iq holds the recorder's raw uint16 samples, decoded on load: gpsmi_acq_set_input_format)
+template <int G, int FMT = 0>
 __global__ __launch_bounds__(256 * G) void acq_spectrum_kernel(
-    const float2* __restrict__ iq, const float* __restrict__ t32,
+    const void* __restrict__ iq, const float* __restrict__ t32,
     const float* __restrict__ omega, int n_avg, float2* __restrict__ spectra,
     const float2* __restrict__ tw) {
     __shared__ __attribute__((aligned(16))) float lds[kFftLdsFloats];
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(256 * G) void acq_spectrum_kernel(
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             int k = i * kFftN + t + 256 * r;
-            float2 x = iq[k];
+            float2 x = load_iq<FMT>(iq, k);
             float p = mul_rn(om, t32[k]);      // float32 phase argument, phase0 = 0
             float s, c;
             sincosf(p, &s, &c);
@@ -121,8 +122,9 @@ __global__ __launch_bounds__(256) void acq_corr_kernel(
 
 // ---- general code length: wipe-off + fold in the time domain ----------------
 // x[bin][m] = (1/n_avg) sum_i iq[i L + m] exp(-j fl32(om t32[i L + m]))
+template <int FMT = 0>
 __global__ __launch_bounds__(256) void acq_fold_kernel(
-    const float2* __restrict__ iq, const float* __restrict__ t32,
+    const void* __restrict__ iq, const float* __restrict__ t32,
     const float* __restrict__ omega, int n_avg, int L, float2* __restrict__ xout) {
     const int m = blockIdx.x * 256 + threadIdx.x, bin = blockIdx.y;
     if (m >= L) return;
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(256) void acq_fold_kernel(
     float ar = 0.f, ai = 0.f;
     for (int i = 0; i < n_avg; ++i) {
         const int k = i * L + m;
-        const float2 v = iq[k];
+        const float2 v = load_iq<FMT>(iq, k);
         float sn, co;
         sincosf(mul_rn(om, t32[k]), &sn, &co);
         ar += co * v.x + sn * v.y;
@@ -199,6 +201,7 @@ struct gpsmi_acq {
     // ... or natively in LDS when the code period is 16368 = 16 * 3 * 11 * 31 samples (gpsmi_pfa.h)
     bool pfa = false;
     float2* d_RSp = nullptr;                // [GPSMI_MAX_PRN + 1][16368] replica spectra, P3's order
+    int iq_fmt = GPSMI_IQ_C64;              // what the iq pointers of the search calls point to
     float last_ms = 0.f;
     bool pending = false;
 };
@@ -418,8 +421,12 @@ static int acq_search_impl(gpsmi_acq* h, const void* d_iq, size_t n, const int32
     GPSMI_HIP(hipEventRecord(h->ev0, h->stream));
     if (h->direct) {
         const int ncell = nbins * nsv;
-        hipLaunchKernelGGL(acq_fold_kernel, dim3((cs + 255) / 256, nbins), dim3(256), 0, h->stream,
-                           (const float2*)d_iq, h->d_t32, h->d_omega, n_avg, cs, h->d_fold);
+        if (h->iq_fmt == GPSMI_IQ_U8)
+            hipLaunchKernelGGL(acq_fold_kernel<1>, dim3((cs + 255) / 256, nbins), dim3(256), 0, h->stream,
+                               d_iq, h->d_t32, h->d_omega, n_avg, cs, h->d_fold);
+        else
+            hipLaunchKernelGGL(acq_fold_kernel<0>, dim3((cs + 255) / 256, nbins), dim3(256), 0, h->stream,
+                               d_iq, h->d_t32, h->d_omega, n_avg, cs, h->d_fold);
         hipLaunchKernelGGL(acq_cells_kernel, dim3((ncell + 255) / 256), dim3(256), 0, h->stream,
                            h->d_xsel, h->d_rsel, h->d_slot, nsv, ncell);
         if (h->pfa)              // transform, product, transform and statistics in one launch
@@ -438,12 +445,19 @@ static int acq_search_impl(gpsmi_acq* h, const void* d_iq, size_t n, const int32
         hipLaunchKernelGGL(acq_peaks_kernel, dim3((ncell + 255) / 256), dim3(256), 0, h->stream,
                            h->d_stats, h->d_peaks, nbr ? h->d_nbr : nullptr, ncell);
     } else {
-        if (n_avg >= 4)
-            hipLaunchKernelGGL(acq_spectrum_kernel<4>, dim3(nbins), dim3(1024), 0, h->stream,
-                               (const float2*)d_iq, h->d_t32, h->d_omega, n_avg, h->d_spec, h->d_tw);
+        const bool u8 = h->iq_fmt == GPSMI_IQ_U8;
+        if (n_avg >= 4 && u8)
+            hipLaunchKernelGGL((acq_spectrum_kernel<4, 1>), dim3(nbins), dim3(1024), 0, h->stream,
+                               d_iq, h->d_t32, h->d_omega, n_avg, h->d_spec, h->d_tw);
+        else if (n_avg >= 4)
+            hipLaunchKernelGGL((acq_spectrum_kernel<4, 0>), dim3(nbins), dim3(1024), 0, h->stream,
+                               d_iq, h->d_t32, h->d_omega, n_avg, h->d_spec, h->d_tw);
+        else if (u8)
+            hipLaunchKernelGGL((acq_spectrum_kernel<1, 1>), dim3(nbins), dim3(256), 0, h->stream,
+                               d_iq, h->d_t32, h->d_omega, n_avg, h->d_spec, h->d_tw);
         else
-            hipLaunchKernelGGL(acq_spectrum_kernel<1>, dim3(nbins), dim3(256), 0, h->stream,
-                               (const float2*)d_iq, h->d_t32, h->d_omega, n_avg, h->d_spec, h->d_tw);
+            hipLaunchKernelGGL((acq_spectrum_kernel<1, 0>), dim3(nbins), dim3(256), 0, h->stream,
+                               d_iq, h->d_t32, h->d_omega, n_avg, h->d_spec, h->d_tw);
         hipLaunchKernelGGL(acq_corr_kernel, dim3(nsv, nbins), dim3(256), 0, h->stream, h->d_spec,
                            h->d_rep, h->d_slot, h->d_peaks, nsv, h->d_tw,
                            nbr ? h->d_nbr : nullptr);
@@ -503,8 +517,19 @@ int gpsmi_acq_search_ex(gpsmi_acq* h, const float* iq, size_t n, const int32_t* 
         GPSMI_HIP(hipMalloc((void**)&h->d_iq, need * sizeof(float2)));
         h->iq_cap = need;
     }
-    GPSMI_HIP(hipMemcpyAsync(h->d_iq, iq, need * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+    // (the staging buffer is sized for complex64; raw input uploads a quarter of it)
+    GPSMI_HIP(hipMemcpyAsync(h->d_iq, iq, need * (h->iq_fmt == GPSMI_IQ_U8 ? 2 : sizeof(float2)),
+                             hipMemcpyHostToDevice, h->stream));
     return acq_search_impl(h, h->d_iq, need, prn, nsv, freqs, nbins, n_avg, out, nullptr, nbr);
+}
+
+int gpsmi_acq_set_input_format(gpsmi_acq* h, int fmt) {
+    GPSMI_REQUIRE(h, "null handle");
+    GPSMI_REQUIRE(fmt == GPSMI_IQ_C64 || fmt == GPSMI_IQ_U8, "unknown input format");
+    GPSMI_HIP(hipSetDevice(h->cfg.device));
+    GPSMI_HIP(hipStreamSynchronize(h->stream));
+    h->iq_fmt = fmt;
+    return GPSMI_OK;
 }
 
 int gpsmi_acq_last_ms(gpsmi_acq* h, float* ms) {

@@ -45,6 +45,19 @@ inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 __device__ __host__ inline float mul_rn(float a, float b) { return a * b; }
 __device__ __host__ inline float add_rn(float a, float b) { return a + b; }
 __device__ __host__ inline float sub_rn(float a, float b) { return a - b; }
+// streamData's sample decode (reference src/gpsrecv.py:168-173) of one raw uint16 (Q << 8 | I):
+// float32(byte) * float32(1 / 127.5) - 1 per component, two roundings, exactly what numpy's
+// portable complex64 loop and gpsmi_dev_unpack_u8iq compute
+__device__ inline float2 decode_u8iq(unsigned v) {
+    const float scl = 1.0f / 127.5f;
+    return make_float2(sub_rn(mul_rn((float)(v & 0xFF), scl), 1.0f), sub_rn(mul_rn((float)(v >> 8), scl), 1.0f));
+}
+// sample k of a block in either input format (FMT 0: complex64, FMT 1: raw uint16)
+template <int FMT>
+__device__ __forceinline__ float2 load_iq(const void* iq, size_t k) {
+    if constexpr (FMT == 0) return static_cast<const float2*>(iq)[k];
+    else return decode_u8iq(static_cast<const uint16_t*>(iq)[k]);
+}
 #pragma clang fp contract(fast)
 
 }  // namespace gpsmi

@@ -352,6 +352,14 @@ struct gpsmi_trk {
     hipStream_t copy_stream = nullptr;   // result read-back, overlaps the next replay run
     hipStream_t epi_stream = nullptr;    // replay: the epilogue of run k beside the code-phase
                                          // correlation of run k + 1 (the other slot's buffers)
+    // streaming from host memory (gpsmi_trk_process_stream): two staging blocks filled on a stream
+    // of their own, so that the upload of block k + 1 runs under the kernels of block k
+    hipStream_t up_stream = nullptr;
+    void* d_stage[2] = {nullptr, nullptr};
+    size_t stage_bytes = 0;
+    hipEvent_t up_done[2] = {nullptr, nullptr}, stage_free[2] = {nullptr, nullptr};
+    bool stage_used[2] = {false, false};
+    int stage_idx = 0;
     hipEvent_t order = nullptr;          // orders other handles' streams behind this one
     hipEvent_t main_tail = nullptr;      // the event recorded behind the last work on `stream`, if any
     // two result slots: a replay run writes one while the other is still being copied out
@@ -497,7 +505,7 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
         const int cg = nblocks * ((nch + h->corr_cg - 1) / h->corr_cg) < 64 ? (nblocks * nch <= 64 ? 1 : 2)
                                                                              : h->corr_cg;
         const int ng = (nch + cg - 1) / cg;
-        const dim3 cgrid(((nblocks + 7) / 8) * 8 * ng);
+        const dim3 cgrid(nblocks < 8 ? nblocks * ng : ((nblocks + 7) / 8) * 8 * ng);
 #define GPSMI_LAUNCH_CORR(CGV)                                                                          \
     do {                                                                                              \
         if (u8)                                                                                       \
@@ -642,6 +650,7 @@ static int trk_take_timing(gpsmi_trk* h, gpsmi_trk::Slot& sl) {
 
 // everything enqueued so far (kernels and read-backs) has finished
 static int trk_settle(gpsmi_trk* h) {
+    if (h->up_stream && (h->stage_used[0] || h->stage_used[1])) GPSMI_HIP(hipStreamSynchronize(h->up_stream));
     GPSMI_HIP(hipStreamSynchronize(h->stream));
     GPSMI_HIP(hipStreamSynchronize(h->epi_stream));
     h->slot[0].epi_pending = h->slot[1].epi_pending = false;
@@ -826,6 +835,13 @@ int gpsmi_trk_destroy(gpsmi_trk* h) {
         if (sl.epi_done) (void)hipEventDestroy(sl.epi_done);
     }
     if (h->order) (void)hipEventDestroy(h->order);
+    if (h->up_stream) (void)hipStreamSynchronize(h->up_stream);
+    for (int k = 0; k < 2; ++k) {
+        if (h->d_stage[k]) (void)hipFree(h->d_stage[k]);
+        if (h->up_done[k]) (void)hipEventDestroy(h->up_done[k]);
+        if (h->stage_free[k]) (void)hipEventDestroy(h->stage_free[k]);
+    }
+    if (h->up_stream) (void)hipStreamDestroy(h->up_stream);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->epi_stream) (void)hipStreamDestroy(h->epi_stream);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -975,6 +991,61 @@ int gpsmi_trk_process(gpsmi_trk* h, const float* iq, size_t n, gpsmi_trk_out* ou
     GPSMI_HIP(hipMemcpyAsync(h->d_block, iq, n * (h->iq_fmt == GPSMI_IQ_U8 ? 2 : sizeof(float2)),
                              hipMemcpyHostToDevice, h->stream));
     return gpsmi_trk_process_dev(h, h->d_block, n, out);
+}
+
+int gpsmi_trk_process_stream(gpsmi_trk* h, const void* iq, size_t n, gpsmi_trk_out* out) {
+    GPSMI_REQUIRE(h && iq, "null argument");
+    GPSMI_REQUIRE(n == (size_t)h->n_streams * h->cfg.n_cyc * h->cfg.code_samples,
+                  "input must hold one block of NGPS samples per stream");
+    GPSMI_HIP(hipSetDevice(h->cfg.device));
+    const size_t bytes = n * (h->iq_fmt == GPSMI_IQ_U8 ? 2 : sizeof(float2));
+    if (!h->up_stream) {
+        GPSMI_HIP(hipStreamCreate(&h->up_stream));
+        for (int k = 0; k < 2; ++k) {
+            GPSMI_HIP(hipEventCreateWithFlags(&h->up_done[k], hipEventDisableTiming));
+            GPSMI_HIP(hipEventCreateWithFlags(&h->stage_free[k], hipEventDisableTiming));
+        }
+    }
+    if (bytes > h->stage_bytes) {
+        int rc = trk_settle(h);
+        if (rc) return rc;
+        for (int k = 0; k < 2; ++k) {
+            if (h->d_stage[k]) GPSMI_HIP(hipFree(h->d_stage[k]));
+            h->d_stage[k] = nullptr;
+            h->stage_used[k] = false;
+        }
+        h->stage_bytes = 0;
+        for (int k = 0; k < 2; ++k) GPSMI_HIP(hipMalloc(&h->d_stage[k], bytes));
+        h->stage_bytes = bytes;
+    }
+    int rc = trk_push_state(h);
+    if (rc) return rc;
+    if (h->slot[0].copy_pending || h->slot[1].copy_pending || h->slot[0].timing_pending ||
+        h->slot[1].timing_pending || h->slot[0].epi_pending || h->slot[1].epi_pending) {
+        rc = trk_settle(h);                 // a replay still in flight owns the slots
+        if (rc) return rc;
+    }
+    const int s = h->stage_idx;
+    h->stage_idx ^= 1;
+    // the block goes up on the upload stream as soon as the kernels that read this staging
+    // block two calls ago have finished; the kernels of this call start behind the upload
+    if (h->stage_used[s]) GPSMI_HIP(hipStreamWaitEvent(h->up_stream, h->stage_free[s], 0));
+    GPSMI_HIP(hipMemcpyAsync(h->d_stage[s], iq, bytes, hipMemcpyHostToDevice, h->up_stream));
+    GPSMI_HIP(hipEventRecord(h->up_done[s], h->up_stream));
+    GPSMI_HIP(hipStreamWaitEvent(h->stream, h->up_done[s], 0));
+    gpsmi_trk::Slot& sl = h->slot[0];
+    h->cur = 0;
+    const bool timing = h->timing;
+    h->timing = false;                      // (no kernel-timing events in a streaming loop)
+    rc = trk_launch(h, sl, h->d_stage[s], h->d_state, h->d_state, nullptr, h->rows(), h->max_ch);
+    h->timing = timing;
+    if (rc) return rc;
+    GPSMI_HIP(hipEventRecord(h->stage_free[s], h->stream));
+    h->stage_used[s] = true;
+    if (out)
+        GPSMI_HIP(hipMemcpyAsync(out, sl.d_out, h->rows() * sizeof(gpsmi_trk_out),
+                                 hipMemcpyDeviceToHost, h->stream));
+    return GPSMI_OK;
 }
 
 int gpsmi_trk_replay_load(gpsmi_trk* h, int nb, const gpsmi_trk_state* table,

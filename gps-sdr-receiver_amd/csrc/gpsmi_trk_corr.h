@@ -87,10 +87,14 @@ __global__ __launch_bounds__(256, (CG > 4 || CG == 1) ? 2 : 3) void trk_corr_ker
     __shared__ CorrFin fin[CG];
     __shared__ float2 vtab[CG][32];              // the factors of V(t), see the prologue
 
+    // batches: the channel groups of a block are neighbours on one XCD (they share its rows through
+    // that L2).  A launch of fewer than 8 blocks (the closed loop) would leave 7 of 8 workgroups with
+    // nothing to do: its grid is exactly nblocks * ngroups and maps linearly.
     const int wg = blockIdx.x;
+    const bool linear = (int)gridDim.x == nblocks * ngroups;
     const int xcd = wg & 7, slot = wg >> 3;
-    const int g = slot % ngroups;
-    const int b = (slot / ngroups) * 8 + xcd;
+    const int g = linear ? wg % ngroups : slot % ngroups;
+    const int b = linear ? wg / ngroups : (slot / ngroups) * 8 + xcd;
     if (b >= nblocks) return;
     const int t = threadIdx.x;
     const int cs = kFftN;

@@ -72,7 +72,8 @@ EXPORTS = [
     'gpsmi_trk_replay_run_async', 'gpsmi_trk_replay_fetch_async', 'gpsmi_trk_wait',
     'gpsmi_trk_wait_prev', 'gpsmi_trk_after_acq', 'gpsmi_acq_after_trk', 'gpsmi_trk_set_timing',
     'gpsmi_trk_last_ms',
-    'gpsmi_trk_set_input_format', 'gpsmi_trk_set_streams',
+    'gpsmi_trk_set_input_format', 'gpsmi_trk_set_streams', 'gpsmi_trk_process_stream',
+    'gpsmi_acq_set_input_format',
     'gpsmi_comm_unique_id', 'gpsmi_comm_create', 'gpsmi_comm_destroy',
     'gpsmi_comm_allgather_peaks',
 ]
@@ -142,6 +143,9 @@ def load():
         'gpsmi_trk_wait_prev': [vp],
         'gpsmi_trk_set_timing': [vp, C.c_int],
         'gpsmi_trk_set_input_format': [vp, C.c_int],
+        'gpsmi_acq_set_input_format': [vp, C.c_int],
+        'gpsmi_trk_set_streams': [vp, C.c_int],
+        'gpsmi_trk_process_stream': [vp, vp, sz, vp],
         'gpsmi_trk_after_acq': [vp, vp],
         'gpsmi_acq_after_trk': [vp, vp],
         'gpsmi_host_alloc': [sz, P(vp)],

@@ -24,9 +24,13 @@ def norm_max_corr(cell):
 class Acquisition:
     """Drop-in for the module-level search functions of gpsrecv.py."""
 
-    def __init__(self, cfg=None, engine=None):
+    def __init__(self, cfg=None, engine=None, raw_u8=False):
+        """raw_u8: `data` of the calls below is the recorder's uint16 (Q << 8 | I) block as
+        streamData reads it (gpsrecv.py:162-173) instead of complex64; it is decoded on the GPU."""
         self.cfg = cfg or Config()
         self.engine = engine or AcqEngine(self.cfg)
+        if raw_u8:
+            self.engine.set_input_format(True)
 
     def bin_frequencies(self, freq, it_sweep):
         """Frequencies one sweepAllSats call visits (gpsrecv.py:248, :267-272),

@@ -157,8 +157,26 @@ class AcqEngine:
                 check(self.lib.gpsmi_acq_set_replica_time(self.h, p, ptr(rep)),
                       'gpsmi_acq_set_replica_time')
 
+    raw_u8 = False
+
+    def set_input_format(self, raw_u8):
+        """raw_u8 = True: the iq of the searches that follow is the recorder's uint16
+        (Q << 8 | I) samples (gpsrecv.py:162-173), decoded inside the wipe-off kernel."""
+        check(self.lib.gpsmi_acq_set_input_format(self.h, 1 if raw_u8 else 0),
+              'gpsmi_acq_set_input_format')
+        self.raw_u8 = bool(raw_u8)
+
+    def _host_iq(self, iq):
+        want = np.uint16 if self.raw_u8 else np.complex64
+        iq = np.asarray(iq)
+        if iq.dtype != want:
+            raise TypeError(f'iq dtype {iq.dtype} does not match the input format '
+                            f'({np.dtype(want).name}; see set_input_format)')
+        return np.ascontiguousarray(iq)
+
     def search(self, iq, prns, freqs, n_avg, out_dev=None):
-        """iq: complex64 numpy array (host) or a (c_void_p, n) device pair.
+        """iq: complex64 numpy array (host; uint16 after set_input_format(True)) or a
+        (c_void_p, n) device pair.
         Returns a structured array [nbins, nsv] of (argmax, peak, mean, std)."""
         prn_a = np.ascontiguousarray(prns, dtype=np.int32)
         f_a = np.ascontiguousarray(freqs, dtype=np.float64)
@@ -169,7 +187,7 @@ class AcqEngine:
                 self.h, d_iq, n, ptr(prn_a), len(prn_a), ptr(f_a), len(f_a),
                 n_avg, ptr(out), out_dev), 'gpsmi_acq_search_dev')
         else:
-            iq = np.ascontiguousarray(iq, dtype=np.complex64)
+            iq = self._host_iq(iq)
             check(self.lib.gpsmi_acq_search(
                 self.h, ptr(iq), iq.size, ptr(prn_a), len(prn_a), ptr(f_a),
                 len(f_a), n_avg, ptr(out)), 'gpsmi_acq_search')
@@ -197,7 +215,7 @@ class AcqEngine:
         f_a = np.ascontiguousarray(freqs, dtype=np.float64)
         out = np.zeros((len(f_a), len(prn_a)), dtype=PEAK_DTYPE)
         nbr = np.zeros((len(f_a), len(prn_a), 2), dtype=np.float32)
-        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        iq = self._host_iq(iq)
         check(self.lib.gpsmi_acq_search_ex(
             self.h, ptr(iq), iq.size, ptr(prn_a), len(prn_a), ptr(f_a), len(f_a),
             n_avg, ptr(out), ptr(nbr)), 'gpsmi_acq_search_ex')
@@ -297,6 +315,17 @@ class TrkEngine:
             check(self.lib.gpsmi_trk_process(self.h, ptr(iq), iq.size, ptr(out)),
                   'gpsmi_trk_process')
         return out
+
+    def process_stream(self, iq, out=None):
+        """One closed-loop block (per stream) from host memory without a host wait: the
+        upload runs on its own stream under the previous block's kernels
+        (gpsmi_trk_process_stream).  iq: a C-contiguous array in the handle's input format,
+        ideally a PinnedArray's; out: optional pinned OUT_DTYPE array, valid after wait()."""
+        n = self.streams * self.cfg.ngps
+        if iq.size != n or iq.dtype != (np.uint16 if getattr(self, 'raw_u8', False) else np.complex64):
+            raise TypeError('block size or dtype does not match the handle')
+        check(self.lib.gpsmi_trk_process_stream(self.h, ptr(iq), n, ptr(out)),
+              'gpsmi_trk_process_stream')
 
     def replay(self, d_iq, nb, table, delay_used=None):
         """nb device-resident blocks, states at block start [nb, max_ch]."""

@@ -23,12 +23,16 @@ UDP_PORT = 61431                # gpsglob.py:82
 
 
 class Receiver:
-    def __init__(self, cfg=None, sat_all=None):
+    def __init__(self, cfg=None, sat_all=None, raw_u8=False):
+        """raw_u8: feed() takes the recorder's uint16 (Q << 8 | I) blocks exactly as streamData
+        reads them from the file (gpsrecv.py:162-173); the decode to complex64 happens inside
+        the GPU kernels, every datagram is byte-identical to the complex64 path's."""
         self.cfg = cfg or Config()
+        self.raw_u8 = bool(raw_u8)
         self.sat_all = list(SAT_ALL if sat_all is None else sat_all)
-        self.acq = Acquisition(self.cfg)
+        self.acq = Acquisition(self.cfg, raw_u8=self.raw_u8)
         self.pool, self.pool_no, self.pool_worker = R.initMultiProcPool(self.cfg.max_sat,
-                                                                        self.cfg)
+                                                                        self.cfg, self.raw_u8)
         self.running = True
         self.smp_time = np.int64(0)                  # SMP_TIME, gpsrecv.py:29
         self.act_sat_set = set()
@@ -52,7 +56,7 @@ class Receiver:
             self.running = False
 
     def feed(self, data, skip=0):
-        """One block (complex64[NGPS]); `skip` = streams lost before it
+        """One block (complex64[NGPS], or uint16[NGPS] when raw_u8); `skip` = streams lost before it
         (gpsrecv.py:469-471).  Returns the pickled hand-off or None."""
         c = self.cfg
         self.skipped_data += skip * c.ngps

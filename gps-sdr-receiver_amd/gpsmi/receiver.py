@@ -182,15 +182,20 @@ class GpuPool:
     """What ``initMultiProcPool`` returns as `pool`: one tracking engine and one
     acquisition engine (for per-channel re-sweeps) instead of a process list."""
 
-    def __init__(self, pool_no, cfg=None):
+    def __init__(self, pool_no, cfg=None, raw_u8=False):
         self.cfg = cfg or Config()
+        self.raw_u8 = bool(raw_u8)          # blocks are the recorder's uint16 samples (fused ingest)
         self.trk = TrkEngine(self.cfg, max_ch=pool_no)
+        if self.raw_u8:
+            self.trk.set_input_format(True)
         self.acq = None
         self.chan = [None] * pool_no        # HostChannel per worker slot
 
     def acq_engine(self):
         if self.acq is None:
             self.acq = AcqEngine(self.cfg)
+            if self.raw_u8:
+                self.acq.set_input_format(True)
         return self.acq
 
     def close(self):
@@ -199,10 +204,11 @@ class GpuPool:
             self.acq.close()
 
 
-def initMultiProcPool(poolNo, cfg=None):
+def initMultiProcPool(poolNo, cfg=None, raw_u8=False):
     """gpsrecv.py:340-360 -> (pool, poolNo, poolWorker); poolWorker[w] is 0 when
-    slot w is free, else the PRN it tracks."""
-    return GpuPool(poolNo, cfg), poolNo, [0] * poolNo
+    slot w is free, else the PRN it tracks.  raw_u8: the blocks given to satCalc are the
+    recorder's uint16 samples, decoded inside the kernels (2 B/sample over PCIe)."""
+    return GpuPool(poolNo, cfg, raw_u8), poolNo, [0] * poolNo
 
 
 def closeMultiProcPool(pool):               # gpsrecv.py:363-367

@@ -41,6 +41,8 @@ extern "C" {
 #define GPSMI_MAX_PRN      37
 #define GPSMI_MAX_DUMPS    33   /* N_CYC + 1 prompt dumps (gpslib.py:1418-1439)  */
 #define GPSMI_MAX_DF       128  /* entries of the PLL drift list (1024 / N_CYC)  */
+#define GPSMI_IQ_C64       0    /* input formats: numpy complex64 (the default) ... */
+#define GPSMI_IQ_U8        1    /* ... or the recorder's uint16 (Q << 8 | I)      */
 
 /* Module constants of gpsglob.py:35-131 that the path depends on. */
 typedef struct gpsmi_cfg {
@@ -135,6 +137,10 @@ int gpsmi_acq_search_dev_async(gpsmi_acq* h, const void* d_iq, size_t n,
                                const double* freqs_hz, int nbins, int n_avg,
                                gpsmi_peak* out, void* out_dev);
 int gpsmi_acq_wait(gpsmi_acq* h);
+/* Input format of the iq pointers of the search calls that follow (host or device), as
+ * gpsmi_trk_set_input_format below: GPSMI_IQ_U8 = the raw recording of streamData
+ * (gpsrecv.py:162-173), decoded where the carrier wipe-off reads it; same bits out.   */
+int gpsmi_acq_set_input_format(gpsmi_acq* h, int fmt);
 /* Timing of the last search on the handle's stream (HIP events), ms.          */
 int gpsmi_acq_last_ms(gpsmi_acq* h, float* ms);
 
@@ -219,6 +225,17 @@ int gpsmi_trk_process(gpsmi_trk* h, const float* iq, size_t n,
 int gpsmi_trk_process_dev(gpsmi_trk* h, const void* d_iq, size_t n,
                           gpsmi_trk_out* out);
 
+/* The same for a stream that arrives in host memory, without a host wait per block: the block
+ * (page-locked memory from gpsmi_host_alloc for a full-rate, truly asynchronous copy; n and the
+ * format as for gpsmi_trk_process) is uploaded into one of two staging blocks on a stream of its
+ * own and the kernels are enqueued behind the upload, so the call returns at once and the upload
+ * of block k + 1 runs under the kernels of block k.  iq must stay untouched until a later call
+ * has returned twice or gpsmi_trk_wait has; out (optional, page-locked) is filled when
+ * gpsmi_trk_wait returns or the call after next has been enqueued and waited for.  This is
+ * streamData -> pushToBuffer -> processData (gpsrecv.py:153-186, :76-104, :445-548) with the ring
+ * buffer's consumer on the GPU.                                                        */
+int gpsmi_trk_process_stream(gpsmi_trk* h, const void* iq, size_t n, gpsmi_trk_out* out);
+
 /* Batched receivers: R independent IQ streams (receivers) tracked by one handle, so that the
  * closed loop -- a chain of three dependent launches per 32-ms block -- fills the GPU with the
  * jobs of R x max_ch channels instead of max_ch.  After the call the handle has R * max_ch state
@@ -235,8 +252,6 @@ int gpsmi_trk_set_streams(gpsmi_trk* h, int n_streams);
  * that read IQ decode on load, bit for bit what gpsmi_dev_unpack_u8iq writes, so every
  * output equals the complex64 path's.  CODE_SAMPLES = 2048 and N_CYC = 32 only
  * (GPSMI_E_UNSUPPORTED otherwise); block sizes are still counted in samples.           */
-#define GPSMI_IQ_C64 0
-#define GPSMI_IQ_U8  1
 int gpsmi_trk_set_input_format(gpsmi_trk* h, int fmt);
 
 /* Replay (open loop): nb blocks resident in device memory, the state at the

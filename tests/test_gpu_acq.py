@@ -135,6 +135,36 @@ def test_device_resident_input_equals_host_input(acq):
     buf.free()
 
 
+@pytest.mark.parametrize('config, cs, n_cyc', [('default', 2048, 32), ('hirate', 16368, 8)])
+def test_raw_u8_search_equals_complex64_search(config, cs, n_cyc):
+    """gpsmi_acq_set_input_format(GPSMI_IQ_U8): the search reads the recorder's uint16 samples
+    (host and device-resident), n_avg = 1 and 4 (the one- and four-group spectrum kernels, the
+    general fold kernel): every peak record equals the complex64 search's, byte for byte."""
+    from conftest import scene_for
+    from gpsmi.acquisition import Acquisition
+    from gpsmi.engine import Config, DeviceBuffer
+    sc = scene_for(config)
+    raw, c64 = sc.block_raw(0), sc.block(0)
+    cfg = Config(code_samples=cs, n_cyc=n_cyc)
+    a, b = Acquisition(cfg), Acquisition(cfg, raw_u8=True)
+    prns = [s.prn for s in sc.sats][:6] + [1]
+    f = [-2000.0, -400.0, 0.0, 1800.0]
+    buf = DeviceBuffer(raw.nbytes)
+    buf.upload(raw)
+    for n_avg in (1, 4):
+        want = a.engine.search(c64, prns, f, n_avg)
+        assert b.engine.search(raw, prns, f, n_avg).tobytes() == want.tobytes(), n_avg
+        assert b.engine.search((buf.ptr, raw.size), prns, f, n_avg).tobytes() == want.tobytes()
+    t1, n1 = a.engine.search_ex(c64, prns, f, 4)
+    t2, n2 = b.engine.search_ex(raw, prns, f, 4)
+    assert t1.tobytes() == t2.tobytes() and n1.tobytes() == n2.tobytes()
+    with pytest.raises(TypeError):
+        b.engine.search(c64, prns, f, 1)
+    buf.free()
+    a.engine.close()
+    b.engine.close()
+
+
 # ---- BASELINE config 5: CODE_SAMPLES = 16368, N_CYC = 8 (time-domain correlation) ----
 
 @pytest.fixture(scope='module')

@@ -97,3 +97,68 @@ def test_skipped_streams_are_reported():
     assert skipped == 2 * 65536
     assert int(rx.smp_time) == (40 + 2) * 65536
     rx.close()
+
+
+def test_raw_u8_flow_equals_complex64_flow():
+    """The reference's own path is file -> streamData's u8 decode -> processData (gpsrecv.py:153-186,
+    :445-548).  Receiver(raw_u8=True) takes the recorder's uint16 blocks as they come off the
+    file; cold search, channel selection, tracking, the per-channel re-sweep and the hand-off
+    must produce byte-identical datagrams to the complex64 path (the decode inside the kernels
+    is the bits of gpsmi_dev_unpack_u8iq / numpy's expression)."""
+    from conftest import scene_for
+    from gpsmi.pipeline import Receiver
+    sc = scene_for('default')
+    n = 40
+    raw = [sc.block_raw(i) for i in range(n)]
+    c64 = scene_blocks('default', 0, n)
+    rx_a, rx_b = Receiver(), Receiver(raw_u8=True)
+    n_out = 0
+    for i in range(n):
+        a, b = rx_a.feed(c64[i]), rx_b.feed(raw[i])
+        assert (a is None) == (b is None), i
+        if a is not None:
+            assert a == b, i                              # the pickled datagrams, byte for byte
+            n_out += 1
+        if i == 30:                                       # a channel re-sweeps on the raw blocks too
+            from gpsmi import receiver as R
+            for rx in (rx_a, rx_b):
+                sno = sorted(rx.act_sat_set)[0]
+                R.initSweep(rx.pool, rx.pool_worker.index(sno))
+    assert n_out >= 1 and rx_a.act_sat_set == rx_b.act_sat_set
+    assert rx_a.found_sats == rx_b.found_sats
+    with pytest.raises(TypeError):
+        rx_b.feed(c64[0])                                 # the wrong format is refused, not cast
+    rx_a.close()
+    rx_b.close()
+
+
+def test_streamed_blocks_equal_blocking_calls():
+    """gpsmi_trk_process_stream: blocks from pinned host memory, upload on its own stream under
+    the previous block's kernels, no host wait per block.  Raw uint16 and complex64 input; the
+    records of every block must equal those of the blocking gpsmi_trk_process."""
+    from conftest import load_golden, scene_for
+    from gpsmi.engine import TrkEngine, PinnedArray, OUT_DTYPE
+    g = load_golden('ref_default.npz')
+    sc = scene_for('default')
+    nch, n = len(g['trk_init']), 10
+    for raw_u8 in (False, True):
+        blocks = [sc.block_raw(5 + i) if raw_u8 else sc.block(5 + i) for i in range(n)]
+        engs = [TrkEngine(max_ch=nch) for _ in range(2)]
+        for e in engs:
+            if raw_u8:
+                e.set_input_format(True)
+            for c, (sv, f0, d0) in enumerate(g['trk_init']):
+                e.open(c, int(sv), float(f0), int(d0))
+        want = [engs[0].process(b).tobytes() for b in blocks]
+        pins = [PinnedArray(blocks[0].shape, blocks[0].dtype) for _ in range(3)]
+        outs = [PinnedArray((nch,), OUT_DTYPE) for _ in range(n)]
+        for i, b in enumerate(blocks):
+            pins[i % 3].array[:] = b                      # (three buffers: one is never rewritten
+            engs[1].process_stream(pins[i % 3].array, outs[i].array)   # while it may still be read)
+        engs[1].wait()
+        for i in range(n):
+            assert outs[i].array.tobytes() == want[i], (raw_u8, i)
+        for e in engs:
+            e.close()
+        for p_ in pins + outs:
+            p_.free()
