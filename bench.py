@@ -289,6 +289,53 @@ def measure_batched(E, local, iq_at, nb_avail, chans, Rs=(1, 8, 32, 64), max_ste
     return res
 
 
+def measure_streamed(E, local, raw_blocks, chans, Rs=(1, 8, 32), steps=48):
+    """The reference's own shape of the flow (file -> streamData -> ring buffer -> processData,
+    gpsrecv.py:153-186, :76-104, :445-548): blocks arrive in (page-locked) host memory and go up
+    inside the timed loop, block k + 1 under the kernels of block k (gpsmi_trk_process_stream),
+    closed loop, state on the device, nothing read back.  Raw uint16 (2 B/sample over PCIe, the
+    decode fused into the kernels) next to complex64 (8 B/sample), R receivers per step."""
+    from gpsmi.synth import raw_to_c64
+    res = []
+    nb = len(raw_blocks)
+    for R in Rs:
+        for raw_u8 in (True, False):
+            trk = E.TrkEngine(E.Config(device=local), max_ch=max(1, len(chans)), streams=R)
+            if raw_u8:
+                trk.set_input_format(True)
+            for r in range(R):
+                for c, (s, f, d) in enumerate(chans):
+                    trk.open(c, s, f, d, stream=r)
+            dt = np.uint16 if raw_u8 else np.complex64
+            ring = [E.PinnedArray((R, NGPS), dt) for _ in range(3)]
+            for k, pin in enumerate(ring):                 # (three distinct slabs of the recording)
+                for r in range(R):
+                    blk = raw_blocks[(k * R + r) % nb]
+                    pin.array[r] = blk if raw_u8 else raw_to_c64(blk)
+            best = None
+            for rep in range(3):
+                E.sync(local)
+                t0 = time.perf_counter()
+                for i in range(steps):
+                    trk.process_stream(ring[i % 3].array)
+                trk.wait()
+                t = (time.perf_counter() - t0) / steps
+                best = t if best is None else min(best, t)
+            trk.close()
+            for pin in ring:
+                pin.free()
+            bps = 2 if raw_u8 else 8
+            res.append({'R': R, 'input': 'raw uint16 (Q<<8|I), 2 B/sample' if raw_u8 else 'complex64, 8 B/sample',
+                        'us_per_step': round(best * 1e6, 2),
+                        'msamples_per_s': round(R * NGPS / best / 1e6, 1),
+                        'pcie_gb_per_s': round(R * NGPS * bps / best / 1e9, 2),
+                        'x_realtime_per_stream': round(NGPS / best / 2.048e6, 1)})
+    return {'config': 'streamed from host: closed loop with the H2D copy of every block inside the timed '
+                      'loop (gpsmi_trk_process_stream, pinned memory, upload of block k + 1 under the '
+                      'kernels of block k), 12 channels per receiver, R receivers per step',
+            'runs': res}
+
+
 # ---------------------------------------------------------------------- main
 def main():
     # stdout carries exactly one JSON line: whatever libraries print there while we run
@@ -582,6 +629,7 @@ def main():
         if world == 1:
             extra.append(measure_u8(E, local, d_raw, nb, chans, states, cl_out['delay_used'], cl_out))
             extra.append(measure_cfg5(E, local))
+            extra.append(measure_streamed(E, local, raw[N_ACQ_BLOCKS:N_ACQ_BLOCKS + 96], chans))
 
     if rank == 0:
         samples = nb * NGPS
