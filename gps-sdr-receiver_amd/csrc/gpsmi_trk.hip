@@ -138,6 +138,22 @@ __device__ inline float np_sum_f32(const float* a, int n) {
     return res;
 }
 
+// The same sum by one wave, every lane returning it: lanes 0..7 each carry one of numpy's eight
+// strided accumulators (n / 8 - 1 dependent adds instead of n), the tree ((r0+r1)+(r2+r3)) +
+// ((r4+r5)+(r6+r7)) is three DPP steps (the adds commute, so the partners of a step hold the same
+// bits), the tail is added in order.  a: LDS, n <= 128.
+__device__ __forceinline__ float np_sum_f32_wave(const float* a, int n, int lane) {
+    if (n < 8) return np_sum_f32(a, n);
+    const int j = lane & 7, body = n - (n % 8);
+    float r = a[j];
+    for (int i = 8; i < body; i += 8) r = add_rn(r, a[i + j]);
+    r = dpp_add0<0xB1, 0xF>(r);          // quad_perm [1,0,3,2]: r0+r1 | r2+r3 | r4+r5 | r6+r7
+    r = dpp_add0<0x4E, 0xF>(r);          // quad_perm [2,3,0,1]: (r0+r1)+(r2+r3) | (r4+r5)+(r6+r7)
+    r = dpp_add0<0x141, 0xF>(r);         // row_half_mirror: lane j with lane 7 - j
+    for (int i = body; i < n; ++i) r = add_rn(r, a[i]);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, r)));
+}
+
 // The per-job part of a block behind the correlator, one wave, lane i = prompt dump i.
 // Element-wise work (windows, |g|, atan, phase unwrapping by a lane prefix sum) is spread
 // over the lanes; the few float32 sums are evaluated redundantly by every lane over small
@@ -182,13 +198,13 @@ __device__ __forceinline__ void epilogue_job(const gpsmi_trk_state& si, gpsmi_tr
     const float mag = hypotf(gr, gi);
     if (lane < nd) s_mag_w[lane] = mag;
     __builtin_amdgcn_wave_barrier();
-    const float mmean = np_sum_f32(s_mag_w, nd) / (float)nd;
+    const float mmean = np_sum_f32_wave(s_mag_w, nd, lane) / (float)nd;
     {
         const float e = sub_rn(mag, mmean);
         if (lane < nd) s_dev_w[lane] = mul_rn(e, e);
     }
     __builtin_amdgcn_wave_barrier();
-    const float sdev = sqrtf(np_sum_f32(s_dev_w, nd) / (float)nd);
+    const float sdev = sqrtf(np_sum_f32_wave(s_dev_w, nd, lane) / (float)nd);
 
     // ---- phaseLockedLoop (gpslib.py:1215-1262): unwrap by a lane prefix sum
     const float ph = atanf(gi / gr);
@@ -207,13 +223,13 @@ __device__ __forceinline__ void epilogue_job(const gpsmi_trk_state& si, gpsmi_tr
     if (lane < nd) s_real_w[lane] = real;
     __builtin_amdgcn_wave_barrier();
     const float offset = np_sum_f32(s_real_w + (nd - 4), 4) / 4.0f;
-    const float pdev = np_sum_f32(s_real_w, nd) / (float)nd;
+    const float pdev = np_sum_f32_wave(s_real_w, nd, lane) / (float)nd;
     const float max_df = 20.0f / (float)P.df_no;
     int locked = was_locked;
     int new_len;
     float df;
     if (locked) {
-        const float mean_df = np_sum_f32(s_df_w, df_len) / (float)df_len;
+        const float mean_df = np_sum_f32_wave(s_df_w, df_len, lane) / (float)df_len;
         df = add_rn(pdev, mean_df);                 // DF_GAIN2 = 1
         if (fabsf(df) > max_df) df = (df > 0.f ? 1.f : -1.f) * max_df;
         const int shift = df_len >= P.df_no ? 1 : 0;   // drop the oldest entry
