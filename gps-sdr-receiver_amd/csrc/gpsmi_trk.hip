@@ -55,8 +55,9 @@ struct TrkParams {
     int df_no;         // 1024 / n_cyc
     float t_last;      // SEC_TIME[NGPS-1]
     float om_min, om_max;   // float32(2*pi*MIN_FREQ), float32(2*pi*MAX_FREQ) from float64
-    int flags;              // diagnostics only (GPSMI_DEBUG_FLAGS): 1 no MAC, 2 no lane sums, 4 no mixed fix
-                            // (vector correlator), 16 the timed span correlator launch is a repeat
+    int flags;              // diagnostics, -DGPSMI_DIAG builds only (`make diag`, GPSMI_DEBUG_FLAGS): 1 no MAC,
+                            // 2 no lane sums, 4 no mixed fix (vector correlator), 32 no fold, 64 no
+                            // transforms (code-phase correlation); the shipped library ignores them
 };
 
 // per-job descriptor handed from the correlation kernel to the correlator and
@@ -69,6 +70,16 @@ struct __attribute__((aligned(32))) JobMid {
     float ph;          // PHASE at the start of the block
     int pad[3];
 };
+
+// a diagnostics bit of TrkParams::flags: constant false in the shipped library
+__device__ __forceinline__ bool diag_flag(const TrkParams& P, int bit) {
+#ifdef GPSMI_DIAG
+    return (P.flags & bit) != 0;
+#else
+    (void)P; (void)bit;
+    return false;
+#endif
+}
 
 __device__ __forceinline__ float wave_sum_t(float v) {
 #pragma unroll
@@ -430,10 +441,10 @@ struct gpsmi_trk {
     int done_by_dispatch = 1;          // GPSMI_DONE_BY_DISPATCH=0: an event record behind the correlator instead
     // code_samples != 2048: time-domain correlation + chunked correlator
     bool general = false;
-    int stream_j = 8;                // code positions per lane of the correlator (8 or 4)
+    static constexpr int stream_j = 8;   // code positions per lane of the vector correlator
     int mfma = 0;                    // MFMA correlator (default where it applies): 4 = span form
-                                     // (gpsmi_trk_span.h); 3 = 32x32x2 form, four waves per workgroup,
-                                     // three workgroups per CU; 1 = the same with eight waves
+                                     // (gpsmi_trk_span.h); 3 = the round-1 32x32x2 form, four waves per
+                                     // workgroup, three workgroups per CU
     float* d_code2 = nullptr;        // [GPSMI_MAX_PRN + 1][2 cs]: replica twice (no index wrap)
     float* d_code_eo = nullptr;      // [GPSMI_MAX_PRN + 1][2][cs]: replica split by index parity, each
                                      // plane twice (span form)
@@ -568,23 +579,17 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
         const int ng12 = (nch + kMfCh - 1) / kMfCh;
         const dim3 mgrid(((nblocks + 7) / 8) * 8 * ng12);
         if (h->mfma == 4 && span_single && u8)
-            hipLaunchKernelGGL((trk_span_kernel<1, 1, 0, 1>), dim3(nblocks * ng12 * 32), dim3(64), 0, h->stream,
+            hipLaunchKernelGGL((trk_span_kernel<1, 1, 1>), dim3(nblocks * ng12 * 32), dim3(64), 0, h->stream,
                                d_iq_v, sl.d_mid, h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
         else if (h->mfma == 4 && span_single)
-            hipLaunchKernelGGL((trk_span_kernel<1, 1, 0, 0>), dim3(nblocks * ng12 * 32), dim3(64), 0, h->stream,
+            hipLaunchKernelGGL((trk_span_kernel<1, 1, 0>), dim3(nblocks * ng12 * 32), dim3(64), 0, h->stream,
                                d_iq_v, sl.d_mid, h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
-        else if (h->mfma == 4 && ext_timed && (P.flags & 16)) {   // diagnostics: the timed launch is a second one
-            hipLaunchKernelGGL((trk_span_kernel<8, 4, 0, 0>), span_grid, dim3(256), 0, h->stream,
-                               d_iq_v, sl.d_mid, h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
-            hipExtLaunchKernelGGL((trk_span_kernel<8, 4, 0, 0>), span_grid, dim3(256), 0, h->stream,
-                                  sl.ev[1], sl.ev[2], 0, d_iq_v, (const JobMid*)sl.d_mid,
-                                  (const float*)h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
-        } else if (h->mfma == 4 && ext_timed && u8)
-            hipExtLaunchKernelGGL((trk_span_kernel<8, 4, 0, 1>), span_grid, dim3(256), 0, h->stream,
+        else if (h->mfma == 4 && ext_timed && u8)
+            hipExtLaunchKernelGGL((trk_span_kernel<8, 4, 1>), span_grid, dim3(256), 0, h->stream,
                                   sl.ev[1], sl.ev[2], 0, d_iq_v, (const JobMid*)sl.d_mid,
                                   (const float*)h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
         else if (h->mfma == 4 && ext_timed)
-            hipExtLaunchKernelGGL((trk_span_kernel<8, 4, 0, 0>), span_grid, dim3(256), 0, h->stream,
+            hipExtLaunchKernelGGL((trk_span_kernel<8, 4, 0>), span_grid, dim3(256), 0, h->stream,
                                   sl.ev[1], sl.ev[2], 0, d_iq_v, (const JobMid*)sl.d_mid,
                                   (const float*)h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
         else if (h->mfma == 4 && side_epilogue && h->done_by_dispatch) {
@@ -592,25 +597,22 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
             // signal of this very dispatch, not a record behind it - a record is one more
             // barrier packet between this kernel and the next batch's first one
             if (u8)
-                hipExtLaunchKernelGGL((trk_span_kernel<8, 4, 0, 1>), span_grid, dim3(256), 0, h->stream,
+                hipExtLaunchKernelGGL((trk_span_kernel<8, 4, 1>), span_grid, dim3(256), 0, h->stream,
                                       nullptr, sl.corr_done, 0, d_iq_v, (const JobMid*)sl.d_mid,
                                       (const float*)h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
             else
-                hipExtLaunchKernelGGL((trk_span_kernel<8, 4, 0, 0>), span_grid, dim3(256), 0, h->stream,
+                hipExtLaunchKernelGGL((trk_span_kernel<8, 4, 0>), span_grid, dim3(256), 0, h->stream,
                                       nullptr, sl.corr_done, 0, d_iq_v, (const JobMid*)sl.d_mid,
                                       (const float*)h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
             corr_done_recorded = true;
         } else if (h->mfma == 4 && u8)
-            hipLaunchKernelGGL((trk_span_kernel<8, 4, 0, 1>), span_grid, dim3(256), 0, h->stream,
+            hipLaunchKernelGGL((trk_span_kernel<8, 4, 1>), span_grid, dim3(256), 0, h->stream,
                                d_iq_v, sl.d_mid, h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
         else if (h->mfma == 4)
-            hipLaunchKernelGGL((trk_span_kernel<8, 4, 0, 0>), span_grid, dim3(256), 0, h->stream,
+            hipLaunchKernelGGL((trk_span_kernel<8, 4, 0>), span_grid, dim3(256), 0, h->stream,
                                d_iq_v, sl.d_mid, h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
-        else if (h->mfma != 1)
-            hipLaunchKernelGGL(trk_stream_mfma_kernel<4>, mgrid, dim3(256), 0, h->stream, d_iq,
-                               sl.d_mid, h->d_code2, P, ng12, nblocks, sl.d_partial);
         else
-            hipLaunchKernelGGL(trk_stream_mfma_kernel<8>, mgrid, dim3(512), 0, h->stream, d_iq,
+            hipLaunchKernelGGL(trk_stream_mfma_kernel<4>, mgrid, dim3(256), 0, h->stream, d_iq,
                                sl.d_mid, h->d_code2, P, ng12, nblocks, sl.d_partial);
     } else {                               // the vector correlator (other block / code lengths)
         const dim3 grid(sgrid.x, h->nchunks), block(kStreamThreads);
@@ -624,13 +626,8 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
         else if (P.n_cyc == 16) GPSMI_LAUNCH_STREAM(16, POW2, J); \
         else GPSMI_LAUNCH_STREAM(8, POW2, J);           \
     } while (0)
-        if (h->general) {
-            if (h->stream_j == 8) GPSMI_LAUNCH_STREAM_NC(false, 8);
-            else GPSMI_LAUNCH_STREAM_NC(false, 4);
-        } else {
-            if (h->stream_j == 8) GPSMI_LAUNCH_STREAM_NC(true, 8);
-            else GPSMI_LAUNCH_STREAM_NC(true, 4);
-        }
+        if (h->general) GPSMI_LAUNCH_STREAM_NC(false, 8);
+        else GPSMI_LAUNCH_STREAM_NC(true, 8);
 #undef GPSMI_LAUNCH_STREAM_NC
 #undef GPSMI_LAUNCH_STREAM
         if (h->nchunks > 1) {
@@ -735,10 +732,6 @@ int gpsmi_trk_create(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk** out) {
     h->cfg = *cfg;
     h->max_ch = max_ch;
     h->general = cfg->code_samples != kFftN;
-    {
-        const char* js = getenv("GPSMI_STREAM_J");
-        if (js && (atoi(js) == 4 || atoi(js) == 8)) h->stream_j = atoi(js);
-    }
     h->nchunks = (cfg->code_samples + 256 * h->stream_j - 1) / (256 * h->stream_j);
     const int rc = trk_build(cfg, max_ch, h);
     if (rc) {                       // nothing half-built leaves this function
@@ -781,10 +774,9 @@ static int trk_build(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk* h) {
     {
         const char* mf = getenv("GPSMI_STREAM_MFMA");
         // default for CS = 2048, N_CYC = 32: the span form of the MFMA correlator;
-        // GPSMI_STREAM_MFMA=3 selects the 32x32x2 form with four waves per workgroup, =1 its
-        // eight-wave form, =0 the vector kernel.  One form per handle: the closed loop and the
+        // GPSMI_STREAM_MFMA=3 selects the 32x32x2 form (round 1), =0 the vector kernel.  One form per handle: the closed loop and the
         // replay of a handle sum in the same order (bytewise equal results).
-        h->mfma = (!h->general && cfg->n_cyc == 32 && !(mf && atoi(mf) == 0)) ? (mf ? atoi(mf) : 4) : 0;
+        h->mfma = (!h->general && cfg->n_cyc == 32 && !(mf && atoi(mf) == 0)) ? (mf && atoi(mf) == 3 ? 3 : 4) : 0;
         if (h->mfma) {
             const size_t b2 = (size_t)(GPSMI_MAX_PRN + 1) * 2 * kFftN * sizeof(float);
             GPSMI_HIP(hipMalloc((void**)&h->d_code2, b2));

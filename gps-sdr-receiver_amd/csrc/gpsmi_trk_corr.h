@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256, (CG > 4 || CG == 1) ? 2 : 3) void trk_corr_ker
         }
     };
     Raw x[kFoldDepth][8];
-    const bool nofold = P.flags & 32;                     // diagnostics: no fold at all
+    const bool nofold = diag_flag(P, 32);                     // diagnostics: no fold at all
     const bool piped = P.corr_avg == kFoldChunk && !nofold;   // any other row count: one row at a time
     if (piped) {
 #pragma unroll
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256, (CG > 4 || CG == 1) ? 2 : 3) void trk_corr_ker
         corr_stats8(mag, t, magbuf, red, bi, bv, mean, sd, elo, ehi);
         if (t == 0) fin[c] = CorrFin{bi, bv, mean, sd, elo, ehi};
     };
-    if (P.flags & 64) {                          // diagnostics: no transforms
+    if (diag_flag(P, 64)) {                          // diagnostics: no transforms
         float sm = 0.f;
 #pragma unroll
         for (int c = 0; c < CG; ++c)

@@ -233,8 +233,9 @@ __device__ __forceinline__ void sp_store_tile(float* tl, int lane, const sp4 (&s
 // first tile of the wave's next range, or a position past the block: nothing).  Returns the
 // sums of the range for [M tile][N tile] in (tot, lo_fin): lo_fin = what was summed below the
 // delay when the boundary lies inside the range, tot = the rest.
-// (DIAG, probes only: 1 no MFMAs, 2 no row loads after the first tile, 8 default cache policy)
-template <int NSPANS, int DIAG = 0, int FMT = 0>
+// (DIAG: tools/probe/span_prof.hip only -- 1 no MFMAs, 2 no row loads after the first tile, 8 default
+// cache policy; the library instantiates DIAG = 0 alone, where every test of it folds away)
+template <int NSPANS, int FMT = 0, int DIAG = 0>
 __device__ __forceinline__ void span_wave(const void* __restrict__ blk, const void* next_blk,
                                           int next_pos, float* tl, float* cd, const SpDesc (&mdd)[2],
                                           const SpDesc& smd, const float* __restrict__ code_eo,
@@ -500,7 +501,7 @@ constexpr int kSpRecFloats = 2 * 16 * 64;              // one wave's record
 constexpr int kSpLoOfs = 16 * 64;                      // lo_fin within it
 
 // (FMT 1: iq holds raw uint16 samples, 2 bytes each, decoded on the way into LDS)
-template <int NSPANS, int WAVES, int DIAG = 0, int FMT = 0>
+template <int NSPANS, int WAVES, int FMT = 0, int DIAG = 0>
 __global__ __launch_bounds__(64 * WAVES, 2) void trk_span_kernel(
     const void* __restrict__ iq_v, const JobMid* __restrict__ mid,
     const float* __restrict__ code_eo, TrkParams P, int ngroups, int nblocks,
@@ -533,7 +534,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void trk_span_kernel(
         const int pos0 = range * NSPANS * kSpTile;
         sp_load_tile<(DIAG & 8) ? 0 : 2, FMT>(blk, pos0, lane, st);   // before anything that depends on the descriptors
         sp_wave_descs(mid + (size_t)b * P.nch + g * kSpCh, P.nch - g * kSpCh, lane, md, smd);
-        span_wave<NSPANS, DIAG, FMT>(blk, blk, kNowhere, tl, tl + kSpTileFloats, md, smd, code_eo, pos0, lane, st,
+        span_wave<NSPANS, FMT, DIAG>(blk, blk, kNowhere, tl, tl + kSpTileFloats, md, smd, code_eo, pos0, lane, st,
                                      tot, lo_fin, all_lo, pb);
         float* o = rec + ((size_t)unit * kRanges + range) * kSpRecFloats + lane;
         const int rel0 = pos0 & (kSpQuarter - 1);
@@ -606,7 +607,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void trk_span_kernel(
         const int next = unit + (int)gridDim.x;
         const bool has_next = next < nunits;
         const char* next_blk = has_next ? iq + (size_t)(next / ngroups) * kBlkBytes : blk;
-        span_wave<NSPANS, DIAG, FMT>(blk, next_blk, has_next ? pos0 : kNowhere, tl, tl + kSpTileFloats, md, smd, code_eo,
+        span_wave<NSPANS, FMT, DIAG>(blk, next_blk, has_next ? pos0 : kNowhere, tl, tl + kSpTileFloats, md, smd, code_eo,
                                 pos0, lane_u, st, tot, lo_fin, all_lo, pb);
         // the hi / lo sums of every row of the quarter into LDS (the wave's own tile area),
         // D[i = 4 (lane / 16) + v][j = lane % 16]

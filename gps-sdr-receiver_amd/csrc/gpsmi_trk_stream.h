@@ -373,7 +373,7 @@ __global__ __launch_bounds__(kStreamThreads, J == 8 ? 2 : 3) void trk_stream_ker
             v2f* xc = xb[rr & 3];
             load_row(xb[(rr + 3) & 3], r + 3);
             // every channel, every element: acc[row] += B * x[row]
-            if (!(P.flags & 1)) {
+            if (!diag_flag(P, 1)) {
                 cmac6_init(acc[0][rr], acc[1][rr], acc[2][rr], acc[3][rr], acc[4][rr], acc[5][rr],
                            B[0][0], B[1][0], B[2][0], B[3][0], B[4][0], B[5][0], xc[0]);
 #pragma unroll
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(kStreamThreads, J == 8 ? 2 : 3) void trk_stream_ker
             }
             // the one mixed wave of a channel: the lo elements of the row belong to the
             // window of the row above
-            if (!(P.flags & 4)) {
+            if (!diag_flag(P, 4)) {
 #pragma unroll
                 for (int c = 0; c < kGroupCh; ++c) {
                     if (kcls[c] == 2) {
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(kStreamThreads, J == 8 ? 2 : 3) void trk_stream_ker
         // ---- sum over the 64 lanes of the wave: transpose through LDS in two rounds of
         // up to 32 columns (6 channels x 4 rows x re/im = 48 values per lane + 12
         // carries), fixed order
-        if (P.flags & 2) {
+        if (diag_flag(P, 2)) {
             if (lane < kTrVals) {
                 const int c = lane / (2 * kPassRows), rr = (lane % (2 * kPassRows)) / 2;
                 float sacc = 0.f;

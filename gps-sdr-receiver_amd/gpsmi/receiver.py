@@ -182,10 +182,10 @@ class GpuPool:
     """What ``initMultiProcPool`` returns as `pool`: one tracking engine and one
     acquisition engine (for per-channel re-sweeps) instead of a process list."""
 
-    def __init__(self, pool_no, cfg=None, raw_u8=False):
+    def __init__(self, pool_no, cfg=None, raw_u8=False, trk=None):
         self.cfg = cfg or Config()
         self.raw_u8 = bool(raw_u8)          # blocks are the recorder's uint16 samples (fused ingest)
-        self.trk = TrkEngine(self.cfg, max_ch=pool_no)
+        self.trk = trk if trk is not None else TrkEngine(self.cfg, max_ch=pool_no)   # (trk: tests)
         if self.raw_u8:
             self.trk.set_input_format(True)
         self.acq = None
@@ -215,13 +215,27 @@ def closeMultiProcPool(pool):               # gpsrecv.py:363-367
     pool.close()
 
 
+def open_worker(pool, wno, sat_no, freq, delay):
+    """('initInst',(satNo,freq,delay)) for worker slot wno (gpsrecv.py:312-321)."""
+    pool.trk.open(wno, sat_no, freq, delay)
+    pool.chan[wno] = HostChannel(sat_no, freq, delay, pool.cfg)
+    return sat_no
+
+
+def close_worker(pool, wno):
+    """('delInst',None) (gpsrecv.py:323-328) -> whether an instance existed."""
+    had = pool.chan[wno] is not None
+    if had and not pool.chan[wno].SWEEP:
+        pool.trk.close_channel(wno)
+    pool.chan[wno] = None
+    return had
+
+
 def delPoolStreams(pool, poolNo, poolWorker, actSatSet, delSatSet):
     """gpsrecv.py:370-382"""
     for sat_no in delSatSet:
         wno = poolWorker.index(sat_no)
-        if pool.chan[wno] is not None and not pool.chan[wno].SWEEP:
-            pool.trk.close_channel(wno)
-        pool.chan[wno] = None
+        close_worker(pool, wno)
         poolWorker[wno] = 0
     return poolWorker, actSatSet - delSatSet
 
@@ -234,9 +248,7 @@ def initPoolStreams(pool, poolNo, poolWorker, actSatSet, newSatSet, foundSats):
                 new_sat = newSatSet.pop()
                 poolWorker[wno] = new_sat
                 _, _, freq, delay = [e for e in foundSats if e[1] == new_sat][0]
-                pool.trk.open(wno, new_sat, freq, delay)
-                pool.chan[wno] = HostChannel(new_sat, freq, delay, pool.cfg)
-                actSatSet.add(new_sat)
+                actSatSet.add(open_worker(pool, wno, new_sat, freq, delay))
                 if len(newSatSet) == 0:
                     break
     return poolWorker, actSatSet

@@ -508,9 +508,41 @@ def run_resweep():
     print(path, os.path.getsize(path), 'bytes')
 
 
+def run_newsats():
+    """gpsrecv.getNewSats (gpsrecv.py:423-440) of the reference itself on seeded inputs ->
+    ref_newsats.json: active set, found list, correlation-quality table -> (delete, new)."""
+    import json
+    import numpy as np
+    gpsglob, gpslib, gpsrecv = _import_reference(2048, 32)
+    rng = np.random.default_rng(423)
+    cases = []
+    for k in range(60):
+        n_found = int(rng.integers(0, 18))
+        sats = [int(s) for s in rng.permutation(np.arange(2, 33))[:n_found]]
+        found = sorted(((float(np.round(rng.uniform(8, 40), 3)), s, float(rng.integers(-25, 25) * 200),
+                         int(rng.integers(0, 2048))) for s in sats), reverse=True)
+        n_act = int(rng.integers(0, 12))
+        act = {int(s) for s in rng.permutation(np.arange(2, 33))[:n_act]}
+        cpq = {}
+        for s in act:
+            if rng.random() < 0.85:          # (a channel may not have reported yet)
+                cpq[s] = (float(rng.choice([-1.0, -0.2, 0.0, 0.4, 1.0])),
+                          float(rng.choice([-1.0, 0.0, 0.25, 1.0])))
+        dele, new = gpsrecv.getNewSats(set(act), [tuple(e) for e in found], dict(cpq))
+        cases.append({'act': sorted(act), 'found': [list(e) for e in found],
+                      'cpq': {str(s): list(v) for s, v in cpq.items()},
+                      'delete': sorted(dele), 'new': sorted(new)})
+    path = os.path.join(GOLD, 'ref_newsats.json')
+    with open(path, 'w') as f:
+        json.dump({'max_sat': int(gpsglob.MAX_SAT), 'cases': cases}, f)
+    print(path, os.path.getsize(path), 'bytes', sum(len(c['new']) for c in cases), 'new in all')
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1:
-        if sys.argv[1] == 'navbits':
+        if sys.argv[1] == 'newsats':
+            run_newsats()
+        elif sys.argv[1] == 'navbits':
             run_navbits()
         elif sys.argv[1] == 'position':
             run_position()
@@ -519,6 +551,7 @@ if __name__ == '__main__':
         else:
             run(sys.argv[1])
     else:
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), 'newsats'])
         subprocess.check_call([sys.executable, os.path.abspath(__file__), 'navbits'])
         subprocess.check_call([sys.executable, os.path.abspath(__file__), 'position'])
         subprocess.check_call([sys.executable, os.path.abspath(__file__), 'resweep'])

@@ -123,37 +123,43 @@ def test_resweep_matches_reference(case):
     R.closeMultiProcPool(pool)
 
 
-def test_resweep_reacquires_a_lost_channel(golden_default):
-    """gpslib.py:1153-1173 + :1350-1380: a channel put into SWEEP finds its
-    satellite again through the acquisition engine and returns to tracking."""
+def test_worker_message_loop_equals_direct_calls(golden_default):
+    """gpsmi.workers: the reference's five worker messages (gpsrecv.runProc, gpsrecv.py:300-337)
+    over queue.Queue, all runInst of a block batched into one gpsmi_trk_process, against the
+    direct calls of gpsmi.receiver on the same blocks -- same tuples, including a channel that is
+    put into its re-sweep (gpslib.py:1153-1173) and comes back."""
     from gpsmi import receiver as R
+    from gpsmi import workers as W
     g = golden_default
-    sv, f0, d0 = g['trk_init'][0]
-    found = [(20.0, int(sv), float(f0), int(d0))]
-    pool, n, worker = R.initMultiProcPool(1)
-    worker, act = R.initPoolStreams(pool, n, worker, set(), {int(sv)}, found)
-    blocks = scene_blocks('default', 5, 6)
-    R.satCalc(act, pool, worker, blocks[0], np.int64(6 * 65536))
-    hc = pool.chan[0]
-    # force the sweep trigger the way initSweep leaves the channel
-    st = pool.trk.get_state(0)
-    hc.setPhaseUnlocked()
-    hc.FREQ_SAVE, hc.DF_SAVE = st['freq'], [0.0]
-    hc.FREQ = pool.cfg.min_freq
-    hc.SWEEP = True
-    pool.trk.close_channel(0)
-    sweeps = []
-    for i in range(1, 4):
-        res = R.satCalc(act, pool, worker, blocks[i], np.int64((6 + i) * 65536))
-        sweeps.append(res[0][0])
-        if not res[0][0]:
-            break
-    assert sweeps[-1] is False and len(sweeps) >= 2        # 40 bins per block from -5000 Hz
-    assert abs(hc.FREQ - f0) <= 200.0
-    assert abs(hc.DELAY - g['trk_delay'][0, len(sweeps)]) <= 2
-    assert res[0][3] >= 0                                  # fitted code phase
-    st = pool.trk.get_state(0)
-    assert st['prn'] == int(sv) and st['delay'] == hc.DELAY
-    res = R.satCalc(act, pool, worker, blocks[4], np.int64(10 * 65536))
-    assert res[0][0] is False and res[0][3] >= 0           # tracking again
-    R.closeMultiProcPool(pool)
+    found = [(n, int(s), f, int(d)) for n, s, f, d in (tuple(r) for r in g['sweep_found'])]
+    nch, nb = 6, 14
+    blocks = scene_blocks('default', 5, nb)
+    runs = []
+    for api in ('direct', 'queues'):
+        if api == 'direct':
+            pool, pool_no, worker = R.initMultiProcPool(nch)
+            init, calc, close = R.initPoolStreams, R.satCalc, R.closeMultiProcPool
+            gpu_pool = pool
+        else:
+            gpu_pool = R.GpuPool(nch)
+            pool, pool_no, worker = W.q_initMultiProcPool(nch, pool=gpu_pool)
+            init, calc, close = W.q_initPoolStreams, W.q_satCalc, W.q_closeMultiProcPool
+        worker, act = init(pool, pool_no, worker, set(), {s for _, s, _, _ in found[:nch]}, found)
+        out = []
+        for i in range(nb):
+            if i == 4:                               # (between two blocks: the loop is idle)
+                R.initSweep(gpu_pool, 0)
+            out.append(calc(act, pool, worker, blocks[i], np.int64((5 + i + 1) * 65536)))
+        runs.append((worker, act, out))
+        close(pool)
+    (w_a, act_a, out_a), (w_b, act_b, out_b) = runs
+    assert w_a == w_b and act_a == act_b
+    swept = False
+    for ra, rb in zip(out_a, out_b):
+        assert len(ra) == len(rb) == nch
+        for (sw_a, s_a, f_a, cp_a, q_a), (sw_b, s_b, f_b, cp_b, q_b) in zip(ra, rb):
+            assert (sw_a, s_a, cp_a) == (sw_b, s_b, cp_b)
+            assert tuple(map(float, q_a)) == tuple(map(float, q_b))
+            assert [sorted(d.items(), key=str) for d in f_a] == [sorted(d.items(), key=str) for d in f_b]
+            swept = swept or sw_a
+    assert swept and not any(r[0] for r in out_a[-1])       # the swept channel tracks again

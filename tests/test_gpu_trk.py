@@ -587,52 +587,6 @@ def test_vector_correlator_agrees_with_the_matrix_one(closed_loop, golden_defaul
     np.testing.assert_allclose(r[1]['dumps'], outs['dumps'], rtol=1e-3, atol=5e-5)
 
 
-def test_matrix_correlator_eight_wave_variant_agrees(closed_loop, monkeypatch):
-    """GPSMI_STREAM_MFMA=1: eight waves per workgroup (256 positions each, one workgroup
-    per CU) instead of four: same products, the float32 sums split in eight instead of
-    four partial chains."""
-    from gpsmi.engine import TrkEngine, DeviceBuffer
-    _, outs, states, blocks = closed_loop
-    nb, nch = 8, outs.shape[1]
-    buf = DeviceBuffer(nb * blocks[0].nbytes)
-    for i in range(nb):
-        buf.upload(blocks[i], i * blocks[i].nbytes)
-    monkeypatch.setenv('GPSMI_STREAM_MFMA', '1')
-    eng = TrkEngine(max_ch=nch)
-    monkeypatch.delenv('GPSMI_STREAM_MFMA')
-    rep = eng.replay(buf.ptr, nb, states[:nb], outs['delay_used'][:nb])
-    eng.close()
-    buf.free()
-    for k in ('mx', 'delay', 'delay_used', 'n_dumps', 'nps', 'phase_locked'):
-        assert np.array_equal(rep[k], outs[:nb][k]), k
-    np.testing.assert_allclose(rep['dumps'], outs[:nb]['dumps'], rtol=2e-5, atol=2e-7)
-    np.testing.assert_allclose(rep['freq'], outs[:nb]['freq'], atol=1e-3)
-
-
-def test_four_positions_per_lane_variant_agrees(closed_loop, monkeypatch):
-    """GPSMI_STREAM_J=4: the correlator with four positions per lane, two position spans
-    per code period and a partial-sum reduction (kept selectable) computes
-    the same windows; only the order of the float32 sums differs."""
-    from gpsmi.engine import TrkEngine, DeviceBuffer
-    _, outs, states, blocks = closed_loop
-    nb, nch = 8, outs.shape[1]
-    monkeypatch.setenv('GPSMI_STREAM_J', '4')
-    monkeypatch.setenv('GPSMI_STREAM_MFMA', '0')
-    eng = TrkEngine(max_ch=nch)
-    monkeypatch.delenv('GPSMI_STREAM_J')
-    monkeypatch.delenv('GPSMI_STREAM_MFMA')
-    buf = DeviceBuffer(nb * blocks[0].nbytes)
-    for i in range(nb):
-        buf.upload(blocks[i], i * blocks[i].nbytes)
-    rep = eng.replay(buf.ptr, nb, states[:nb], outs['delay_used'][:nb])
-    buf.free()
-    eng.close()
-    for k in ('mx', 'delay', 'delay_used', 'n_dumps', 'nps', 'phase_locked'):
-        assert np.array_equal(rep[k], outs[:nb][k]), k
-    np.testing.assert_allclose(rep['dumps'], outs[:nb]['dumps'], rtol=2e-5, atol=2e-7)
-    np.testing.assert_allclose(rep['freq'], outs[:nb]['freq'], atol=1e-3)
-
-
 def test_time_domain_correlation_variant_agrees(closed_loop_hirate, golden_hirate, monkeypatch):
     """GPSMI_DIRECT_CORR=1: the exact time-domain correlation kernel (the fall-back for
     code periods beyond 16384 samples) against the same reference fixture as the

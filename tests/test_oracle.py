@@ -169,3 +169,25 @@ def test_get_new_sats():
     assert dele == set() and new == set()      # 11 kept, 5 is the one refill
     dele, new = orc.get_new_sats({3}, found, {3: (-1.0, -1.0)}, 11)
     assert dele == {3} and new == {5, 7, 9}
+
+
+def test_get_new_sats_matches_reference():
+    """tests/golden/ref_newsats.json: gpsrecv.getNewSats of the reference itself
+    (gpsrecv.py:423-440) on 60 seeded (active set, found list, quality table) inputs; the
+    oracle's and the product's restatements must return the same sets."""
+    import json
+    import os
+    from conftest import GOLDEN
+    from gpsmi.acquisition import getNewSats
+    with open(os.path.join(GOLDEN, 'ref_newsats.json')) as f:
+        fix = json.load(f)
+    assert fix['max_sat'] == 11 and len(fix['cases']) == 60
+    n_new = 0
+    for c in fix['cases']:
+        found = [tuple(e) for e in c['found']]
+        cpq = {int(s): tuple(v) for s, v in c['cpq'].items()}
+        for fn in (orc.get_new_sats, getNewSats):
+            dele, new = fn(set(c['act']), list(found), dict(cpq), fix['max_sat'])
+            assert sorted(dele) == c['delete'] and sorted(new) == c['new']
+        n_new += len(c['new'])
+    assert n_new > 100

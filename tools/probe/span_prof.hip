@@ -69,7 +69,7 @@ static void launch_span_t(const Bufs& B, int nblocks, int nch, bool collect) {
         const int per = (grid + g_slots - 1) / g_slots;
         grid = (grid + per - 1) / per;
     }
-    hipLaunchKernelGGL((trk_span_kernel<NSP, WAVES, DIAG>), dim3(grid), dim3(64 * WAVES), 0, 0, B.iq, B.mid,
+    hipLaunchKernelGGL((trk_span_kernel<NSP, WAVES, 0, DIAG>), dim3(grid), dim3(64 * WAVES), 0, 0, B.iq, B.mid,
                        B.code_eo, P, ng, nblocks, B.rec, B.partial);
     if (collect && NSP * WAVES != 32)
         hipLaunchKernelGGL(collect_kernel<NSP>, dim3((nblocks * nch + 3) / 4), dim3(256), 0, 0, B.rec, B.mid, ng,
