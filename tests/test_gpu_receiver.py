@@ -154,12 +154,12 @@ def test_worker_message_loop_equals_direct_calls(golden_default):
         close(pool)
     (w_a, act_a, out_a), (w_b, act_b, out_b) = runs
     assert w_a == w_b and act_a == act_b
-    swept = False
     for ra, rb in zip(out_a, out_b):
         assert len(ra) == len(rb) == nch
         for (sw_a, s_a, f_a, cp_a, q_a), (sw_b, s_b, f_b, cp_b, q_b) in zip(ra, rb):
             assert (sw_a, s_a, cp_a) == (sw_b, s_b, cp_b)
             assert tuple(map(float, q_a)) == tuple(map(float, q_b))
             assert [sorted(d.items(), key=str) for d in f_a] == [sorted(d.items(), key=str) for d in f_b]
-            swept = swept or sw_a
-    assert swept and not any(r[0] for r in out_a[-1])       # the swept channel tracks again
+    # (the swept channel found its satellite again: a hit inside the first call ends the sweep at once)
+    assert not any(r[0] for r in out_a[-1])
+    assert out_a[4][[r[1] for r in out_a[4]].index(w_a[0])][3] != out_a[3][[r[1] for r in out_a[3]].index(w_a[0])][3]
