@@ -336,6 +336,92 @@ def measure_streamed(E, local, raw_blocks, chans, Rs=(1, 8, 32), steps=48):
             'runs': res}
 
 
+def measure_multi(E, sharding, dist, torch, lib, comm, rank, world, local, a, nb, trk_base, d_iq,
+                  chans_all, states, cl_out, gather_peaks, cells, dt_mine, acq_ms, by_channel):
+    """What an N > 1 run reports besides the headline (all ranks call this, after the timed
+    region): the size of the RCCL communicator as RCCL reports it, every rank's own rate, the
+    gather's own time, and north_star's channel split of the same tracking job next to the
+    time-sharded headline.  Nothing here is part of `value`."""
+    import ctypes as C
+    out = {'world': world}
+    # ---- the collective really spans the ranks
+    n_r, my_r = C.c_int(0), C.c_int(-1)
+    if comm is not None and lib.gpsmi_comm_count(comm, C.byref(n_r), C.byref(my_r)) == 0:
+        out['rccl_ranks'] = int(n_r.value)
+        t = torch.tensor([int(my_r.value)], dtype=torch.int64)
+        allr = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allr, t)
+        out['rccl_user_ranks'] = [int(x[0]) for x in allr]
+    else:
+        out['rccl_ranks'] = None                 # rehearsal / RCCL unavailable: see `collective`
+    # ---- every rank's own step time (the headline takes the slowest)
+    t = torch.tensor([dt_mine / a.steps], dtype=torch.float64)
+    allt = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(allt, t)
+    per = [float(x[0]) for x in allt]
+    nch_rank = len(chans_all) if not by_channel else None
+    out['per_rank_ms_per_step'] = [round(x * 1e3, 4) for x in per]
+    out['per_rank_msamples_per_s'] = [round(nb * NGPS / x / 1e6, 1) for x in per]
+    out['one_gpu_equivalent_msamples_per_s'] = round(nb * NGPS / per[0] / 1e6, 1)
+    # ---- the gather alone: equal counts agreed on the host first, then 20 calls
+    sharding.agree_on_count(dist, cells)
+    dist.barrier()
+    E.sync(local)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        gather_peaks()
+    tg = torch.tensor([(time.perf_counter() - t0) / 20], dtype=torch.float64)
+    dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+    out['gather_us'] = round(float(tg[0]) * 1e6, 1)
+    out['gather_bytes_per_rank'] = cells * 16
+    if acq_ms:
+        ta = torch.tensor([float(np.mean(acq_ms))], dtype=torch.float64)
+        dist.all_reduce(ta, op=dist.ReduceOp.MAX)
+        out['sharded_search_us'] = round(float(ta[0]) * 1e3, 1)
+    # ---- north_star's split: the channels round-robin over the ranks, every rank all NB blocks
+    if states is not None:
+        mine = sharding.shard_channels(len(chans_all), rank, world)
+        ms = None
+        if mine:
+            trk2 = E.TrkEngine(E.Config(device=local), max_ch=len(mine))
+            for c, ci in enumerate(mine):
+                s, f, d = chans_all[ci]
+                trk2.open(c, s, f, d)
+            trk2.replay_load(nb, np.ascontiguousarray(states[:, mine]),
+                             np.ascontiguousarray(cl_out['delay_used'][:, mine]))
+            pin = E.PinnedArray((nb, len(mine)), E.OUT_DTYPE)
+            for _ in range(5):
+                trk2.replay_run(d_iq.at(trk_base), nb)
+        dist.barrier()
+        if mine:
+            E.sync(local)
+            t0 = time.perf_counter()
+            for _ in range(20):
+                trk2.replay_run_async(d_iq.at(trk_base), nb)
+                trk2.replay_fetch_async(pin.array)
+                trk2.wait_prev()
+            trk2.wait()
+            ms = (time.perf_counter() - t0) / 20
+            ok_ch = bool(pin.array.tobytes() == np.ascontiguousarray(cl_out[:, mine]).tobytes())
+            trk2.close()
+            pin.free()
+        tc = torch.tensor([ms or 0.0, 1.0 if (not mine or ok_ch) else 0.0], dtype=torch.float64)
+        tmax = tc.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tmin = tc.clone()
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        out['channel_sharded'] = {
+            'what': f'the same {len(chans_all)}-channel job cut by channel (north_star, one worker per '
+                    'SV as in the reference): every rank tracks its channels over all '
+                    f'{nb} blocks, slowest rank',
+            'channels_per_rank': [len(sharding.shard_channels(len(chans_all), r, world))
+                                  for r in range(world)],
+            'ms_per_step': round(float(tmax[0]) * 1e3, 4),
+            'msamples_per_s': round(nb * NGPS / float(tmax[0]) / 1e6, 1) if float(tmax[0]) > 0 else None,
+            'scaling': 'strong', 'outputs_equal_unsharded': bool(float(tmin[1]) == 1.0)}
+    return out
+
+
 # ---------------------------------------------------------------------- main
 def main():
     # stdout carries exactly one JSON line: whatever libraries print there while we run
@@ -585,6 +671,7 @@ def main():
         record_last()
     trk.set_timing(True)
     if dist is not None:
+        dt_mine = dt
         tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt[0])
@@ -623,6 +710,12 @@ def main():
                 merged_out = sharding.merge_channel_outputs(per, len(chans_all), world)
                 checks['merged_channels'] = int((merged_out[-1]['prn'] > 0).sum())
 
+    multi = None
+    if dist is not None:
+        multi = measure_multi(E, sharding, dist, torch, lib, comm, rank, world, local, a, nb,
+                              trk_base, d_iq, chans_all, states if not by_channel else None,
+                              cl_out if not by_channel else None, gather_peaks, cells, dt_mine,
+                              acq_ms, by_channel)
     extra = []
     if rank == 0 and not a.no_extra:
         extra.append(measure_cfg4(E, acq, d_iq0.ptr))
@@ -698,6 +791,7 @@ def main():
                                 'bytewise equal to its solo closed loop (tests/test_gpu_trk.py)',
             },
             'configs': extra,
+            'multi_gpu': multi,
             'checks': checks,
             'device': dev_name,
             'setup_s': {'generate_iq': round(t_gen, 2)},

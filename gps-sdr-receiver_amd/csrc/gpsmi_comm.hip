@@ -71,6 +71,16 @@ int gpsmi_comm_destroy(gpsmi_comm* c) {
     return GPSMI_OK;
 }
 
+int gpsmi_comm_count(gpsmi_comm* c, int* nranks, int* rank) {
+    GPSMI_REQUIRE(c && nranks, "null argument");
+    int n = 0, r = 0;
+    GPSMI_NCCL(ncclCommCount(c->comm, &n));         // what RCCL itself says, not what create was told
+    GPSMI_NCCL(ncclCommUserRank(c->comm, &r));
+    *nranks = n;
+    if (rank) *rank = r;
+    return GPSMI_OK;
+}
+
 int gpsmi_comm_allgather_peaks(gpsmi_comm* c, const void* d_send, void* d_recv, int count,
                                gpsmi_peak* host_recv) {
     GPSMI_REQUIRE(c && d_send && d_recv, "null argument");

@@ -75,7 +75,7 @@ EXPORTS = [
     'gpsmi_trk_set_input_format', 'gpsmi_trk_set_streams', 'gpsmi_trk_process_stream',
     'gpsmi_acq_set_input_format',
     'gpsmi_comm_unique_id', 'gpsmi_comm_create', 'gpsmi_comm_destroy',
-    'gpsmi_comm_allgather_peaks',
+    'gpsmi_comm_allgather_peaks', 'gpsmi_comm_count',
 ]
 
 _lib = None
@@ -155,6 +155,7 @@ def load():
         'gpsmi_comm_create': [vp, C.c_int, C.c_int, C.c_int, P(vp)],
         'gpsmi_comm_destroy': [vp],
         'gpsmi_comm_allgather_peaks': [vp, vp, vp, C.c_int, vp],
+        'gpsmi_comm_count': [vp, P(C.c_int), P(C.c_int)],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)

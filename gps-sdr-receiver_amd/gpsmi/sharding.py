@@ -75,3 +75,22 @@ def merge_peak_tables(gathered, prns, world):
         n = len(shard_svs(prns, r, world))
         cols.append(gathered[r][:, :n])
     return np.concatenate(cols, axis=1)
+
+
+class CountMismatch(ValueError):
+    """The ranks do not agree on the size of a collective (the GPSMI_E_ARG of the host side)."""
+
+
+def agree_on_count(dist, count):
+    """Every rank of a collective must contribute the same number of records: RCCL (like NCCL)
+    does not return from an all-gather whose ranks disagree.  One tiny host-side reduction
+    (the process group the launcher already set up: gloo) before the GPU collective turns that
+    hang into an error on EVERY rank.  dist: torch.distributed (initialised); returns count."""
+    import torch
+    t = torch.tensor([int(count), -int(count)], dtype=torch.int64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)            # (max count, -min count)
+    hi, lo = int(t[0]), -int(t[1])
+    if hi != lo:
+        raise CountMismatch(f'ranks disagree on the record count of the gather: {lo} .. {hi} '
+                            f'(this rank: {int(count)})')
+    return int(count)

@@ -315,7 +315,12 @@ int gpsmi_comm_unique_id(void* id_bytes);             /* rank 0, then broadcast 
 int gpsmi_comm_create(const void* id_bytes, int nranks, int rank, int device,
                       gpsmi_comm** out);
 int gpsmi_comm_destroy(gpsmi_comm* c);
-/* all-gather of `count` peak records per rank; d_send [count], d_recv
+/* The communicator's size and this process's rank as RCCL reports them (ncclCommCount,
+ * ncclCommUserRank): evidence that the collective really spans the ranks.        */
+int gpsmi_comm_count(gpsmi_comm* c, int* nranks, int* rank);
+/* all-gather of `count` peak records per rank: every rank must pass the SAME count (a
+ * collective with unequal counts does not return; gpsmi.sharding.agree_on_count checks it on
+ * the host before the call, as bench.py does); d_send [count], d_recv
  * [nranks*count], both device pointers; host_recv (optional) gets a copy.     */
 int gpsmi_comm_allgather_peaks(gpsmi_comm* c, const void* d_send, void* d_recv,
                                int count, gpsmi_peak* host_recv);

@@ -146,3 +146,42 @@ def test_shards_tile_the_sv_list():
         for r in range(world):
             mine, n, width = sharding.padded_shard(prns, r, world)
             assert len(mine) == width == -(-32 // world) and mine[:n] == sharding.shard_svs(prns, r, world)
+
+
+def _worker_count_mismatch(rank, world, port, q):
+    sys.path[:0] = [os.path.join(ROOT, 'gps-sdr-receiver_amd')]
+    import torch.distributed as dist
+    from gpsmi import sharding
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    events = []
+    # a consistent count passes on every rank ...
+    events.append(('ok', sharding.agree_on_count(dist, 804)))
+    # ... a rank with a different count makes EVERY rank raise before any GPU collective is
+    # entered (RCCL would not return from it), and the group stays usable afterwards
+    try:
+        sharding.agree_on_count(dist, 804 if rank != 1 else 803)
+        events.append(('no error', None))
+    except sharding.CountMismatch as e:
+        events.append(('mismatch', '803 .. 804' in str(e)))
+    events.append(('ok', sharding.agree_on_count(dist, 12)))
+    dist.barrier()
+    q.put((rank, events))
+    dist.destroy_process_group()
+
+
+def test_unequal_gather_counts_raise_on_every_rank_instead_of_hanging():
+    import multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    world = 2
+    procs = [ctx.Process(target=_worker_count_mismatch, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in range(world):
+        assert got[rank] == [('ok', 804), ('mismatch', True), ('ok', 12)], rank
