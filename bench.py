@@ -69,7 +69,10 @@ HBM_COPY_GBS = 6290.0          # same guide: measured float4 copy
 SEED = 7
 TIMED_EVERY = 4                # steps between two kernel-timed steps
 N_CH = 12
-PMC_FILE = os.path.join('profiles', 'round2', 'replay_pmc_counters.txt')
+PMC_FILE = os.path.join('profiles', 'round3', 'pmc_counters.txt')
+ISSUE_CYCLES = 4.9             # measured cycles per packed-fp32 VALU instruction of one wave's stream
+                               # (tools/probe/hazard_probe.hip); the FFT kernels are made of those
+ISSUE_CLOCK_GHZ = 2.2          # the clock DESIGN section 4.4 priced its 78 us floor at
 
 
 def pmc_traffic(kernel):
@@ -94,6 +97,38 @@ def pmc_traffic(kernel):
         return int(fetch * 1024 * 2 + (write or 0) * 1024), PMC_FILE
     except OSError:
         return None, None
+
+
+def pmc_counter(kernel, counter):
+    """Mean of `counter` per launch of the first kernel whose name contains `kernel` in the
+    committed PMC summary (PMC_FILE; None if absent).  Not a measurement of the present run."""
+    try:
+        take = False
+        for line in open(os.path.join(ROOT, PMC_FILE)):
+            if not line.startswith(' '):
+                take = kernel in line
+            elif take and line.split()[0] == counter:
+                return float(line.split()[1])
+    except OSError:
+        pass
+    return None
+
+
+def issue_roofline(kernels, duration_ms, label):
+    """For kernels bound by what their SIMDs can issue (the LDS-resident FFT kernels): the time
+    their VALU instructions need at the measured issue cost on all 1024 SIMDs, over the duration.
+    kernels: [(name fragment in the PMC summary, launches per measured duration)]."""
+    n = 0.0
+    for k, times in kernels:
+        v = pmc_counter(k, 'SQ_INSTS_VALU')
+        n = None if (v is None or n is None) else n + v * times
+    if n is None or not duration_ms:
+        return {'kernel': label, 'bound': 'valu issue', 'frac': None, 'note': 'no PMC summary at ' + PMC_FILE}
+    floor_ms = n / 1024.0 * ISSUE_CYCLES / (ISSUE_CLOCK_GHZ * 1e6)
+    return {'kernel': label, 'bound': 'valu issue', 'valu_instructions_per_launch': int(n),
+            'issue_cycles_per_instruction': ISSUE_CYCLES, 'clock_ghz': ISSUE_CLOCK_GHZ,
+            'floor_ms': round(floor_ms, 4), 'duration_ms': round(duration_ms, 4),
+            'frac': round(floor_ms / duration_ms, 4), 'counter_source': PMC_FILE}
 
 
 # ---------------------------------------------------------------- input data
@@ -185,7 +220,9 @@ def measure_cfg4(E, acq, d_iq, reps=10):
                       '(all 32 SVs)',
             'us_per_search': round(t * 1e3, 1), 'searches_per_s': round(1e3 / t, 1),
             'cells': 32 * 201, 'msamples_per_s': round(20480 / t / 1e3, 2),
-            'bound': 'LDS / VALU (FFT); algorithmic HBM bytes 0.75 MB per search'}
+            'bound': 'LDS / VALU (FFT); algorithmic HBM bytes 0.75 MB per search',
+            'issue_roofline': issue_roofline([('acq acq_spectrum_kernel<4', 1), ('acq acq_corr_kernel', 1)], t,
+                                             'configs[3] search: acq_spectrum_kernel<4> + acq_corr_kernel')}
 
 
 def measure_u8(E, local, d_raw, nb, chans, states, delay_used, expect, iters=8):
@@ -238,21 +275,28 @@ def measure_cfg5(E, local, iters=8):
     st['phase'] = rng.uniform(0, 6.28, (nb, N_CH)).astype(np.float32)
     dly = np.broadcast_to(st['delay'][0], (nb, N_CH)).copy()
     trk.replay_load(nb, st, dly)
-    tot, cor = [], []
+    tot, cor, cph = [], [], []
     for i in range(iters + 2):
         trk.replay_run(buf.ptr, nb)
         if i >= 2:
             t, c = trk.last_ms()
             tot.append(t)
             cor.append(c)
+            cph.append(trk.last_codephase_ms())
     trk.close()
     buf.free()
-    t, c = float(np.median(tot)), float(np.median(cor))
+    t, c, cp = float(np.median(tot)), float(np.median(cor)), float(np.median(cph))
     gb = nb * ngps * 8 / 1e9
     return {'config': 'BASELINE configs[4]: 12-channel tracking @ 16.368 Msps, N_CYC = 8, '
                       f'{nb} blocks x {ngps} complex64 = 512 MiB resident, replay',
             'correlator_ms': round(c, 4), 'correlator_gbs': round(gb / c * 1e3, 1),
             'correlator_frac_of_hbm_peak': round(gb / c * 1e3 / HBM_PEAK_GBS, 4),
+            'codephase_ms': round(cp, 4),
+            'codephase_note': 'wipe-off + fold of all 8 rows for 12 channels (96 flop per 8-byte sample, as '
+                              'much arithmetic as the correlator), then one native-length 16368-point '
+                              '(16 x 3 x 11 x 31) LDS correlation with fused statistics per job',
+            'issue_roofline': issue_roofline([('hirate trk_fold_general_kernel', 1), ('pfa_corr_kernel<0>', 1)], cp,
+                                             'configs[4] code-phase correlation: trk_fold_general_kernel + pfa_corr_kernel'),
             'tracking_all_ms': round(t, 4),
             'msamples_per_s': round(nb * ngps / t / 1e3, 1),
             'x_realtime': round(nb * ngps / t / 1e3 / 16.368, 1)}
@@ -594,10 +638,16 @@ def main():
     acq_pin = E.PinnedArray((len(acq_freqs), width), E.PEAK_DTYPE)
     acq_n = acq_navg * 2048
 
-    def record_last():
+    cold_corr_ms, cp_ms = [], []
+
+    def record_last(cold=False):
         t, c = trk.last_ms()
+        if cold:
+            cold_corr_ms.append(c)
+            return
         total_ms.append(t)
         corr_ms.append(c)
+        cp_ms.append(trk.last_codephase_ms())
 
     def gather_peaks():
         """all-gather of the (padded, equal-sized) shard tables -> `gathered`"""
@@ -640,7 +690,7 @@ def main():
         trk.replay_fetch_async(pins[k & 1].array)
         trk.wait_prev()
         if record and k > 0 and (k - 1) % TIMED_EVERY == 0:
-            record_last()
+            record_last(cold=record == 'cold')
 
     # Settling: an idle MI355X needs some 40 ms under load before its clocks stop moving - the
     # same correlator launch takes ~120 us at the start of a run and ~103 us from the 100th
@@ -648,8 +698,10 @@ def main():
     # started cold would measure the ramp, not the kernels, so the device is first driven with
     # the very step that is timed (a.settle_steps of them, the count is in the JSON line); the
     # W warm-up steps and the K timed steps follow unchanged.
+    # (the correlator launches of the first 24 of them are timed: `roofline.frac_cold`, what a run
+    # that starts its clock on an idle device sees)
     for k in range(a.settle_steps):
-        step(k, False)
+        step(k, 'cold' if k < 26 else False)
     if a.settle_steps:
         finish_search()
         trk.wait()
@@ -771,13 +823,26 @@ def main():
                 'kernel_ms_source': 'hipExtLaunchKernel begin/end events, mean of the timed steps',
                 'algorithmic_bytes_per_launch': alg_bytes,
                 'frac_vs_measured_copy': round(achieved / HBM_COPY_GBS, 4),
+                'frac_cold': round(alg_bytes / (float(np.mean(cold_corr_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                if cold_corr_ms else round(achieved / HBM_PEAK_GBS, 4),
+                'frac_cold_note': 'the same kernel over the first ~25 steps from an idle device '
+                                  '(settle_steps = 0 makes the timed region itself that)',
                 'step_hbm_frac': round(alg_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             },
             'kernels_ms': {
                 'tracking_all': round(float(np.mean(total_ms)), 4),
                 'correlator': round(k_ms, 4),
                 'acquisition_search': round(float(np.mean(acq_ms)), 4),
+                'codephase_correlation': round(float(np.mean(cp_ms)), 4),
             },
+            'issue_rooflines': [
+                issue_roofline([('replay trk_corr_kernel<4, 0>', 1)], float(np.mean(cp_ms)),
+                               'trk_corr_kernel<4,0> inside the step (the search and the previous '
+                               'epilogue run beside it)'),
+                issue_roofline([('acq2 acq_spectrum_kernel<1', 1), ('acq2 acq_corr_kernel', 1)],
+                               float(np.mean(acq_ms)),
+                               'configs[1] search inside the step: acq_spectrum_kernel<1> + acq_corr_kernel'),
+            ] if world == 1 else None,
             'closed_loop': {
                 'value': round(samples / t_closed / 1e6, 1),
                 'unit': 'Msamples/s',

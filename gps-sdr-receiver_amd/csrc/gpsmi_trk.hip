@@ -434,7 +434,7 @@ struct gpsmi_trk {
     gpsmi_trk_state* d_tab_in = nullptr;
     gpsmi_trk_state* d_tab_out = nullptr;
     int* d_forced = nullptr;
-    float last_total_ms = 0.f, last_corr_ms = 0.f;
+    float last_total_ms = 0.f, last_corr_ms = 0.f, last_cp_ms = 0.f;
     int replay_nb = 0;
     bool replay_forced = false;
     int corr_cg = 4;
@@ -672,6 +672,7 @@ static int trk_take_timing(gpsmi_trk* h, gpsmi_trk::Slot& sl) {
     if (!sl.timing_pending) return GPSMI_OK;
     GPSMI_HIP(hipEventElapsedTime(&h->last_total_ms, sl.ev[0], sl.ev[3]));
     GPSMI_HIP(hipEventElapsedTime(&h->last_corr_ms, sl.ev[1], sl.ev[2]));
+    GPSMI_HIP(hipEventElapsedTime(&h->last_cp_ms, sl.ev[0], sl.ev[1]));
     sl.timing_pending = false;
     return GPSMI_OK;
 }
@@ -1001,6 +1002,7 @@ int gpsmi_trk_process_dev(gpsmi_trk* h, const void* d_iq, size_t n, gpsmi_trk_ou
     if (h->timing) {
         GPSMI_HIP(hipEventElapsedTime(&h->last_total_ms, sl.ev[0], sl.ev[3]));
         GPSMI_HIP(hipEventElapsedTime(&h->last_corr_ms, sl.ev[1], sl.ev[2]));
+        GPSMI_HIP(hipEventElapsedTime(&h->last_cp_ms, sl.ev[0], sl.ev[1]));
     }
     return GPSMI_OK;
 }
@@ -1233,6 +1235,12 @@ int gpsmi_trk_last_ms(gpsmi_trk* h, float* total_ms, float* correlator_ms) {
     GPSMI_REQUIRE(h, "null handle");
     if (total_ms) *total_ms = h->last_total_ms;
     if (correlator_ms) *correlator_ms = h->last_corr_ms;
+    return GPSMI_OK;
+}
+
+int gpsmi_trk_last_codephase_ms(gpsmi_trk* h, float* ms) {
+    GPSMI_REQUIRE(h && ms, "null argument");
+    *ms = h->last_cp_ms;
     return GPSMI_OK;
 }
 

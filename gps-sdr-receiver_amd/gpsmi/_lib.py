@@ -71,7 +71,7 @@ EXPORTS = [
     'gpsmi_trk_replay_run', 'gpsmi_trk_replay_fetch', 'gpsmi_trk_replay_states',
     'gpsmi_trk_replay_run_async', 'gpsmi_trk_replay_fetch_async', 'gpsmi_trk_wait',
     'gpsmi_trk_wait_prev', 'gpsmi_trk_after_acq', 'gpsmi_acq_after_trk', 'gpsmi_trk_set_timing',
-    'gpsmi_trk_last_ms',
+    'gpsmi_trk_last_ms', 'gpsmi_trk_last_codephase_ms',
     'gpsmi_trk_set_input_format', 'gpsmi_trk_set_streams', 'gpsmi_trk_process_stream',
     'gpsmi_acq_set_input_format',
     'gpsmi_comm_unique_id', 'gpsmi_comm_create', 'gpsmi_comm_destroy',
@@ -151,6 +151,7 @@ def load():
         'gpsmi_host_alloc': [sz, P(vp)],
         'gpsmi_host_free': [vp],
         'gpsmi_trk_last_ms': [vp, P(f32), P(f32)],
+        'gpsmi_trk_last_codephase_ms': [vp, P(f32)],
         'gpsmi_comm_unique_id': [vp],
         'gpsmi_comm_create': [vp, C.c_int, C.c_int, C.c_int, P(vp)],
         'gpsmi_comm_destroy': [vp],

@@ -405,6 +405,11 @@ class TrkEngine:
         check(self.lib.gpsmi_trk_last_ms(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def last_codephase_ms(self):
+        a = C.c_float(0)
+        check(self.lib.gpsmi_trk_last_codephase_ms(self.h, C.byref(a)))
+        return a.value
+
     def close(self):
         if self.h:
             self.lib.gpsmi_trk_destroy(self.h)

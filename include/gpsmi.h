@@ -304,6 +304,9 @@ int gpsmi_trk_replay_states(gpsmi_trk* h, gpsmi_trk_state* states, size_t n);
  * that does not read gpsmi_trk_last_ms switches them off, a benchmark samples.   */
 int gpsmi_trk_set_timing(gpsmi_trk* h, int on);
 int gpsmi_trk_last_ms(gpsmi_trk* h, float* total_ms, float* correlator_ms);
+/* ... and from the start of the call's device work to the start of its correlator: the
+ * code-phase correlation (cacodeCorr, gpslib.py:1315-1327) with everything in front of it.  */
+int gpsmi_trk_last_codephase_ms(gpsmi_trk* h, float* ms);
 
 /* ========================================================================
  * Multi-GPU: one process per GPU; SVs / blocks are sharded by the host and

@@ -13,7 +13,7 @@ for f in sorted(glob.glob(root + '/**/*counter_collection.csv', recursive=True))
         k = row['Kernel_Name'].split('(')[0].replace('gpsmi::', '')
         tag = f[len(root):].strip('/').split('/')[0]
         tag = tag.split('_pass')[0] if '_pass' in tag else ''
-        if not any(w in k for w in ('stream', 'span', 'corr', 'epilogue')):
+        if not any(w in k for w in ('stream', 'span', 'corr', 'epilogue', 'acq_', 'pfa', 'fold', 'big_')):
             continue
         acc[(tag + ' ' + k).strip()][row['Counter_Name']].append(float(row['Counter_Value']))
 for k, d in acc.items():
