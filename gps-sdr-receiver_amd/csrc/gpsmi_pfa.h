@@ -202,7 +202,13 @@ __global__ __launch_bounds__(kPfaThreads) void pfa_corr_kernel(
     const int cell = MODE == 0 ? cell0 + (int)blockIdx.x : cell0;
     const int sig = pfa_sigma(t < kPfaC ? t : 0);
     __shared__ fft_c tw16[16];                    // exp(+2 pi i m / 16)
+    __shared__ fft_c trig31[31];                  // (cos, sin)(2 pi m / 31) for P3's split lines
     if (t < 16) tw16[t] = pfa_w16(t, false);
+    if (MODE == 0 && t >= 32 && t < 63) {
+        float sn, cs;
+        sincospif(2.0f * (float)(t - 32) / 31.0f, &sn, &cs);
+        trig31[t - 32] = fft_c{cs, sn};
+    }
     __syncthreads();
     PFA_STAMP(0);
 
@@ -235,12 +241,18 @@ __global__ __launch_bounds__(kPfaThreads) void pfa_corr_kernel(
     PFA_STAMP(2);
 
     // ---- P3: Z_31, x conj(replica spectrum), Z_31 again
-    if (t < kPfaLines31) {
-        fft_c* line = data + (t % 16) * kPfaPitch + ((t / 16) % 3) * kPfaS3 + (t / 48) * kPfaS11;
-        fft_c v[31];
+    // 528 lines = eight full waves + 16 lines.  A ninth wave for those 16 would give one SIMD three
+    // waves of ~1400 instructions against two on the others (18 K of the kernel's 46 K cycles were this
+    // phase).  The 16 lines left over go to waves 8..11 instead, 16 lanes per line: lane s forms the
+    // output pair (s, 31 - s) (s = 0: X_0) with the roots read from an LDS table by (n s) mod 31 --
+    // ~450 instructions per wave, one such wave per SIMD.  (MODE 1, one workgroup per replica, keeps
+    // the plain form.)
+    if (MODE == 1) {
+        if (t < kPfaLines31) {
+            fft_c* line = data + (t % 16) * kPfaPitch + ((t / 16) % 3) * kPfaS3 + (t / 48) * kPfaS11;
+            fft_c v[31];
 #pragma unroll
-        for (int i = 0; i < 31; ++i) v[i] = line[i];
-        if (MODE == 1) {
+            for (int i = 0; i < 31; ++i) v[i] = line[i];
             float2* dst = RS + (size_t)cell * kPfaL + t;
             pfa_dft_prime<31>(
                 v, PfaNoPre{}, [&](fft_c X0) { dst[0] = make_float2(X0.x, X0.y); },
@@ -248,36 +260,71 @@ __global__ __launch_bounds__(kPfaThreads) void pfa_corr_kernel(
                     dst[(size_t)k * kPfaLines31] = make_float2(Xk.x, Xk.y);
                     dst[(size_t)(31 - k) * kPfaLines31] = make_float2(Xpk.x, Xpk.y);
                 });
-            return;
-        } else {
-            // the replica spectrum of this line, two pairs ahead of their use
-            const float2* R = RS + (size_t)rsel[cell] * kPfaL + t;
-            float2 r0 = R[0];
-            float2 ra[3], rb[3];
-            ra[1] = R[1 * kPfaLines31]; rb[1] = R[30 * kPfaLines31];
-            ra[2] = R[2 * kPfaLines31]; rb[2] = R[29 * kPfaLines31];
-            pfa_dft_prime<31>(
-                v,
-                [&](int k) {
-                    if (k + 2 <= 15) {
-                        ra[(k + 2) % 3] = R[(size_t)(k + 2) * kPfaLines31];
-                        rb[(k + 2) % 3] = R[(size_t)(31 - k - 2) * kPfaLines31];
-                    }
-                },
-                [&](fft_c X0) { line[0] = cmulp_conj(X0, fft_c{r0.x, r0.y}); },
-                [&](int k, fft_c Xk, fft_c Xpk) {
-                    line[k] = cmulp_conj(Xk, fft_c{ra[k % 3].x, ra[k % 3].y});
-                    line[31 - k] = cmulp_conj(Xpk, fft_c{rb[k % 3].x, rb[k % 3].y});
-                });
-            // (the line belongs to this thread alone: no barrier, the LDS queue is in order)
+        }
+        return;
+    } else if (t < 512) {
+        fft_c* line = data + (t % 16) * kPfaPitch + ((t / 16) % 3) * kPfaS3 + (t / 48) * kPfaS11;
+        fft_c v[31];
 #pragma unroll
-            for (int i = 0; i < 31; ++i) v[i] = line[i];
-            pfa_dft_prime<31>(
-                v, PfaNoPre{}, [&](fft_c X0) { line[0] = X0; },
-                [&](int k, fft_c Xk, fft_c Xpk) { line[k] = Xk; line[31 - k] = Xpk; });
+        for (int i = 0; i < 31; ++i) v[i] = line[i];
+        // the replica spectrum of this line, two pairs ahead of their use
+        const float2* R = RS + (size_t)rsel[cell] * kPfaL + t;
+        float2 r0 = R[0];
+        float2 ra[3], rb[3];
+        ra[1] = R[1 * kPfaLines31]; rb[1] = R[30 * kPfaLines31];
+        ra[2] = R[2 * kPfaLines31]; rb[2] = R[29 * kPfaLines31];
+        pfa_dft_prime<31>(
+            v,
+            [&](int k) {
+                if (k + 2 <= 15) {
+                    ra[(k + 2) % 3] = R[(size_t)(k + 2) * kPfaLines31];
+                    rb[(k + 2) % 3] = R[(size_t)(31 - k - 2) * kPfaLines31];
+                }
+            },
+            [&](fft_c X0) { line[0] = cmulp_conj(X0, fft_c{r0.x, r0.y}); },
+            [&](int k, fft_c Xk, fft_c Xpk) {
+                line[k] = cmulp_conj(Xk, fft_c{ra[k % 3].x, ra[k % 3].y});
+                line[31 - k] = cmulp_conj(Xpk, fft_c{rb[k % 3].x, rb[k % 3].y});
+            });
+        // (the line belongs to this thread alone: no barrier, the LDS queue is in order)
+#pragma unroll
+        for (int i = 0; i < 31; ++i) v[i] = line[i];
+        pfa_dft_prime<31>(
+            v, PfaNoPre{}, [&](fft_c X0) { line[0] = X0; },
+            [&](int k, fft_c Xk, fft_c Xpk) { line[k] = Xk; line[31 - k] = Xpk; });
+    } else if (t < 768) {
+        const int s = t & 15, lid = 512 + ((t - 512) >> 4);        // output pair, line (as thread `lid` of the plain form)
+        fft_c* line = data + (lid % 16) * kPfaPitch + ((lid / 16) % 3) * kPfaS3 + (lid / 48) * kPfaS11;
+        const float2* R = RS + (size_t)rsel[cell] * kPfaL + lid;
+        const float2 rk = R[(size_t)s * kPfaLines31], rpk = R[(size_t)(s ? 31 - s : 0) * kPfaLines31];
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            fft_c v[31];
+#pragma unroll
+            for (int i = 0; i < 31; ++i) v[i] = line[i];            // (16 lanes read one line: broadcasts)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // every lane has the line before any writes it
+            __builtin_amdgcn_wave_barrier();
+            fft_c A = v[0], B = fft_c{0.f, 0.f};
+            int idx = 0;
+#pragma unroll
+            for (int n = 1; n <= 15; ++n) {
+                idx += s;
+                idx = idx >= 31 ? idx - 31 : idx;
+                const fft_c w = trig31[idx];                         // (cos, sin)(2 pi n s / 31)
+                A += (v[n] + v[31 - n]) * w.x;
+                B += (v[n] - v[31 - n]) * w.y;
+            }
+            fft_c Xk = cadd_mi(A, B), Xpk = cadd_pi(A, B);           // s = 0: B = 0, both are X_0
+            if (pass == 0) {
+                Xk = cmulp_conj(Xk, fft_c{rk.x, rk.y});
+                Xpk = cmulp_conj(Xpk, fft_c{rpk.x, rpk.y});
+            }
+            line[s] = Xk;
+            if (s) line[31 - s] = Xpk;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
         }
     }
-    if (MODE == 1) return;
     __syncthreads();
     PFA_STAMP(3);
 

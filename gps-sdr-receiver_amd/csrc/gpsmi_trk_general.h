@@ -20,9 +20,12 @@ namespace gpsmi {
 // for sample k = i cs + m, exp(-j(phase + w t[k])) = U[i] V(m) with U[i] = exp(-j w i T) uniform
 // over a row and V(m) = exp(-j(phase + w (m + 1) / fs)), so a sample costs one complex
 // multiply-accumulate per channel (instead of a sine and a cosine of a float32 argument of up
-// to ~1000 rad), every row is fetched from HBM once for all channels (the groups of four
-// re-read it from L1 / L2), and V is applied once per position and channel.
-constexpr int kGenFoldCh = 4;        // channels per pass over the rows
+// to ~1000 rad) and V is applied once per position and channel.  The rows of a position are
+// loaded ONCE, into registers, and serve every channel of the block (round 2 re-read them per
+// group of four channels: 1.5 GB of reads for 0.5 GB of samples made the kernel HBM-bound at
+// 0.45 ms per 512-block batch); the row factors of up to kGenFoldCh channels wait in LDS.
+constexpr int kGenFoldCh = 16;       // channels per pass over the row-factor tables
+constexpr int kGenFoldRows = 8;      // rows held in registers (CORR_AVG of the reference)
 
 __global__ __launch_bounds__(256) void trk_fold_general_kernel(
     const float2* __restrict__ iq, const float* __restrict__ t32,
@@ -39,8 +42,14 @@ __global__ __launch_bounds__(256) void trk_fold_general_kernel(
     const float2* blk = iq + (size_t)b * ((size_t)cs * P.n_cyc) + (size_t)first * cs + (m < cs ? m : 0);
     const float sc = 1.0f / (float)P.corr_avg;
     const float tm = (float)(m + 1) / (1000.0f * (float)cs);              // (m + 1) / fs
+    const bool in_regs = P.corr_avg == kGenFoldRows;
+    float2 xr[kGenFoldRows];
+    if (in_regs) {
+#pragma unroll
+        for (int i = 0; i < kGenFoldRows; ++i) xr[i] = blk[(size_t)i * cs];
+    }
     for (int c0 = 0; c0 < nch; c0 += kGenFoldCh) {
-        // ---- the group's constants and job descriptors
+        // ---- the pass's constants and job descriptors
         if (t < kGenFoldCh) {
             const int ch = c0 + t;
             int active = 0;
@@ -64,40 +73,40 @@ __global__ __launch_bounds__(256) void trk_fold_general_kernel(
             s_om[t] = om; s_ph[t] = ph; s_active[t] = active;
         }
         __syncthreads();
-        if (t < kGenFoldCh * P.corr_avg) {
-            const int c = t / P.corr_avg, i = t % P.corr_avg;
+        for (int e = t; e < kGenFoldCh * P.corr_avg; e += 256) {
+            const int c = e / P.corr_avg, i = e % P.corr_avg;
             const double rev = (double)s_om[c] * inv_2pi * (double)(first + i) * 1.0e-3;   // w i T / 2 pi
             urow[c][i] = phasor_rev((float)(rev - rint(rev)));
         }
         __syncthreads();
         if (m < cs) {
-            float2 acc[kGenFoldCh];
+            const int npass = nch - c0 < kGenFoldCh ? nch - c0 : kGenFoldCh;
+            for (int c = 0; c < npass; ++c) {
+                float2 acc = make_float2(0.f, 0.f);
+                if (in_regs) {
 #pragma unroll
-            for (int c = 0; c < kGenFoldCh; ++c) acc[c] = make_float2(0.f, 0.f);
-            for (int i = 0; i < P.corr_avg; ++i) {
-                const float2 x = blk[(size_t)i * cs];
-#pragma unroll
-                for (int c = 0; c < kGenFoldCh; ++c) {
-                    const float2 u = urow[c][i];
-                    acc[c].x = fmaf(u.x, x.x, fmaf(-u.y, x.y, acc[c].x));
-                    acc[c].y = fmaf(u.x, x.y, fmaf(u.y, x.x, acc[c].y));
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < kGenFoldCh; ++c) {
-                const int ch = c0 + c;
-                if (ch < nch) {
-                    float2 r = make_float2(0.f, 0.f);
-                    if (s_active[c]) {
-                        const float f_eff = (float)((double)s_om[c] * inv_2pi);
-                        const float2 v = phasor_rev(fmaf(f_eff, tm, s_ph[c] * (float)inv_2pi));
-                        r = cmulf(make_float2(acc[c].x * sc, acc[c].y * sc), v);
+                    for (int i = 0; i < kGenFoldRows; ++i) {
+                        const float2 u = urow[c][i], x = xr[i];
+                        acc.x = fmaf(u.x, x.x, fmaf(-u.y, x.y, acc.x));
+                        acc.y = fmaf(u.x, x.y, fmaf(u.y, x.x, acc.y));
                     }
-                    fold[(size_t)(b * nch + ch) * cs + m] = r;
+                } else {
+                    for (int i = 0; i < P.corr_avg; ++i) {
+                        const float2 u = urow[c][i], x = blk[(size_t)i * cs];
+                        acc.x = fmaf(u.x, x.x, fmaf(-u.y, x.y, acc.x));
+                        acc.y = fmaf(u.x, x.y, fmaf(u.y, x.x, acc.y));
+                    }
                 }
+                float2 r = make_float2(0.f, 0.f);
+                if (s_active[c]) {
+                    const float f_eff = (float)((double)s_om[c] * inv_2pi);
+                    const float2 v = phasor_rev(fmaf(f_eff, tm, s_ph[c] * (float)inv_2pi));
+                    r = cmulf(make_float2(acc.x * sc, acc.y * sc), v);
+                }
+                fold[(size_t)(b * nch + c0 + c) * cs + m] = r;
             }
         }
-        __syncthreads();                                   // (the tables are rewritten for the next group)
+        __syncthreads();                                   // (the tables are rewritten for the next pass)
     }
 }
 

@@ -10,7 +10,7 @@ root = sys.argv[1]
 acc = defaultdict(lambda: defaultdict(list))
 for f in sorted(glob.glob(root + '/**/*counter_collection.csv', recursive=True)):
     for row in csv.DictReader(open(f)):
-        k = row['Kernel_Name'].split('(')[0].replace('gpsmi::', '')
+        k = row['Kernel_Name'].split('(')[0].replace('gpsmi::', '').replace('void ', '')
         tag = f[len(root):].strip('/').split('/')[0]
         tag = tag.split('_pass')[0] if '_pass' in tag else ''
         if not any(w in k for w in ('stream', 'span', 'corr', 'epilogue', 'acq_', 'pfa', 'fold', 'big_')):

@@ -7,7 +7,7 @@ f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 grp = int(sys.argv[2]) if len(sys.argv) > 2 else 25
 rows = []
 for r in csv.DictReader(open(f)):
-    if 'trk_span_kernel<8, 4, 0>' in r['Kernel_Name'] or 'trk_corr_kernel<4, 0>' in r['Kernel_Name']:
+    if 'trk_span_kernel<8, 4, 0' in r['Kernel_Name'] or 'trk_corr_kernel<4, 0>' in r['Kernel_Name']:
         rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), 'span' if 'span' in r['Kernel_Name'] else 'corr'))
 rows.sort()
 t0 = rows[0][0]

@@ -5,7 +5,7 @@ for r in csv.DictReader(open(f)):
     name=r['Kernel_Name'].split('(')[0].replace('void ','').replace('gpsmi::','')
     rows.append((int(r['Start_Timestamp']),int(r['End_Timestamp']),name))
 rows.sort()
-spans=[r for r in rows if r[2].startswith('trk_span_kernel<8, 4, 0>')]
+spans=[r for r in rows if r[2].startswith('trk_span_kernel<8, 4, 0')]
 corrs=[r for r in rows if r[2].startswith('trk_corr_kernel<4, 0>')]
 import bisect
 cs=[c[0] for c in corrs]
