@@ -154,7 +154,7 @@ __device__ __forceinline__ void pfa_dft_prime(fft_c* x, Pre pre, Out0 out0, Out 
 // every workgroup, into a buffer nothing else reads
 #ifdef GPSMI_PFA_STAMPS
 __device__ unsigned long long* g_pfa_stamps;
-#define PFA_STAMP(i) do { if (t == 0) g_pfa_stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PFA_STAMP(i) do { if (t == 0) g_pfa_stamps[(size_t)cell * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define PFA_STAMP(i) do {} while (0)
 #endif
@@ -194,12 +194,16 @@ __device__ __forceinline__ void pfa_slab33(fft_c* base) {
 template <int MODE>
 __global__ __launch_bounds__(kPfaThreads) void pfa_corr_kernel(
     const float2* __restrict__ x, const float* __restrict__ rep, const int* __restrict__ xsel,
-    const int* __restrict__ rsel, float2* __restrict__ RS, int cell0, DirStats* __restrict__ out) {
+    const int* __restrict__ rsel, float2* __restrict__ RS, int cell0, int ncell, DirStats* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) fft_c data[16 * kPfaPitch];
-    __shared__ float red_s[16], red_v[16], red_d[16], nbr[2];
+    __shared__ float red_s[16], red_v[16], red_d[16];
     __shared__ int red_i[16];
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    const int cell = MODE == 0 ? cell0 + (int)blockIdx.x : cell0;
+    // MODE 0: the workgroups are persistent (one per CU: the LDS image admits no second one) and
+    // take every gridDim-th cell; the samples of the next cell are requested before the statistics
+    // of the current one, so only a workgroup's first cell waits for memory at its start
+    int cell = MODE == 0 ? cell0 + (int)blockIdx.x : cell0;
+    const int cell_end = MODE == 0 ? cell0 + ncell : cell0 + 1;
     const int sig = pfa_sigma(t < kPfaC ? t : 0);
     __shared__ fft_c tw16[16];                    // exp(+2 pi i m / 16)
     __shared__ fft_c trig31[31];                  // (cos, sin)(2 pi m / 31) for P3's split lines
@@ -210,28 +214,60 @@ __global__ __launch_bounds__(kPfaThreads) void pfa_corr_kernel(
         trig31[t - 32] = fft_c{cs, sn};
     }
     __syncthreads();
-    PFA_STAMP(0);
-
-    // ---- P1: load, FFT-16 along Z_16, coordinate twiddle, scatter to LDS
-    if (t < kPfaC) {
-        fft_c v[16];
-        if (MODE == 0) {
-            const float2* xv = x + (size_t)xsel[cell] * kPfaL + t;
+    fft_c nx[16];                                 // MODE 0: the samples of `cell`, requested one cell ahead
+    // (buffer loads: one scalar base per cell, ONE lane offset for the sixteen loads, the row
+    // distance in the instruction's scalar offset -- sixteen 64-bit lane addresses would not fit
+    // beside the magnitudes the request is issued next to; a lane past the 1023rd reads nothing)
+    auto request = [&](int c) {
+        if (MODE == 0 && c < cell_end) {
+            const int sel = __builtin_amdgcn_readfirstlane(xsel[c]);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float2*>(x) + (size_t)sel * kPfaL, 0, kPfaL * (int)sizeof(float2), 0x00020000);
+            const int voff = (t < kPfaC ? t : kPfaL) * (int)sizeof(float2);
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const float2 a = xv[kPfaC * j];
-                v[j] = fft_c{a.x, a.y};
+                typedef float pfa_f2 __attribute__((ext_vector_type(2)));
+                nx[j] = __builtin_bit_cast(fft_c, __builtin_amdgcn_raw_buffer_load_b64(
+                    rs, voff, j * kPfaC * (int)sizeof(float2), 0));
             }
-        } else {
-            const float* rv = rep + (size_t)cell * kPfaL + t;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = fft_c{rv[kPfaC * j], 0.f};
         }
-        pfa_fft16(v);
-        data[sig] = v[0];
+    };
+    // P1: FFT-16 along Z_16 of the samples in `nx` (MODE 1: of the real replica), coordinate
+    // twiddle, scatter to LDS
+    auto p1 = [&]() {
+        // (an opaque copy of the thread index per call: the two inlined copies of this phase must not
+        // share their fifteen twiddle indices and addresses across the whole loop through registers)
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        const int sig = pfa_sigma(t < kPfaC ? t : 0);
+        if (t < kPfaC) {
+            if (MODE == 1) {
+                const float* rv = rep + (size_t)cell * kPfaL + t;
 #pragma unroll
-        for (int k = 1; k < 16; ++k) data[k * kPfaPitch + sig] = cmulp(v[k], tw16[(t * k) & 15]);
-    }
+                for (int j = 0; j < 16; ++j) nx[j] = fft_c{rv[kPfaC * j], 0.f};
+            }
+            pfa_fft16(nx);
+            data[sig] = nx[0];
+#pragma unroll
+            for (int k = 1; k < 16; ++k) {
+                data[k * kPfaPitch + sig] = cmulp(nx[k], tw16[(t * k) & 15]);
+                if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (the twiddle reads four at a time:
+            }                                                          //  all fifteen at once cost a spill)
+        }
+    };
+    request(cell);
+    PFA_STAMP(0);
+    p1();
+    // (the loop body starts behind P1: the samples requested for the next cell are live through P5
+    // and the statistics only, not through the register-hungry middle phases)
+#pragma unroll 1
+    for (;;) {
+    // (the thread index is made opaque per cell: hipcc otherwise hoists every address of the five
+    // phases out of the loop and spills 66 registers to keep them)
+    int t_opaque = threadIdx.x;
+    asm volatile("" : "+v"(t_opaque));
+    const int t = t_opaque, wave = t >> 6, lane = t & 63;
+    const int sig = pfa_sigma(t < kPfaC ? t : 0);
     __syncthreads();
     PFA_STAMP(1);
 
@@ -333,9 +369,13 @@ __global__ __launch_bounds__(kPfaThreads) void pfa_corr_kernel(
     __syncthreads();
     PFA_STAMP(4);
 
-    // ---- P5: coordinate twiddle, FFT-16, magnitudes at lag n = t + 1023 j, statistics
-    float mag[16];
-    float sm = 0.f, bv = -1.f;
+    // ---- P5: coordinate twiddle, FFT-16, magnitudes at lag n = t + 1023 j, statistics.
+    // Sum, sum of squares and first-index maximum are formed as the magnitudes appear; each
+    // magnitude goes back into the LDS slot its spectrum value came from (the thread's own 16
+    // slots: no other thread touches them in this phase), from where the peak's two neighbours are
+    // picked up later.  Nothing of the transform stays in registers: the next cell's 16 samples
+    // per thread are requested right here and arrive under the reductions and barriers.
+    float sm = 0.f, s2 = 0.f, bv = -1.f;
     int bi = 0x7fffffff;
     if (t < kPfaC) {
         fft_c v[16];
@@ -345,78 +385,71 @@ __global__ __launch_bounds__(kPfaThreads) void pfa_corr_kernel(
         pfa_fft16(v);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            mag[j] = __builtin_amdgcn_sqrtf(v[j].x * v[j].x + v[j].y * v[j].y) * (1.0f / kPfaL);
-            sm += mag[j];
-            if (mag[j] > bv) { bv = mag[j]; bi = t + kPfaC * j; }     // ascending lag: strict >
+            const float p2 = v[j].x * v[j].x + v[j].y * v[j].y;
+            const float m = __builtin_amdgcn_sqrtf(p2) * (1.0f / kPfaL);
+            sm += m;
+            s2 += p2;
+            if (m > bv) { bv = m; bi = t + kPfaC * j; }               // ascending lag: strict >
+            data[j * kPfaPitch + sig].x = m;
         }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) mag[j] = 0.f;
     }
     PFA_STAMP(5);
+    request(cell + (MODE == 0 ? (int)gridDim.x : 1));
     sm = wave_sum_dpp(sm);
+    s2 = wave_sum_dpp(s2);
     wave_argmax_dpp(bv, bi);
-    if (lane == 0) { red_s[wave] = sm; red_v[wave] = bv; red_i[wave] = bi; }
-    __syncthreads();
-    sm = 0.f; bv = red_v[0]; bi = red_i[0];
-#pragma unroll
-    for (int w = 0; w < 16; ++w) sm += red_s[w];
-#pragma unroll
-    for (int w = 1; w < 16; ++w) {
-        const float ov = red_v[w];
-        const int oi = red_i[w];
-        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-    }
-    const float mean = sm * (1.0f / kPfaL);
-    float d2 = 0.f;
-    if (t < kPfaC) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { const float d = mag[j] - mean; d2 += d * d; }
-    }
-    d2 = wave_sum_dpp(d2);
-    if (lane == 0) red_d[wave] = d2;
-    // the two circular neighbours of the peak, each handed over by the thread that holds it
-    const int nlo = bi > 0 ? bi - 1 : kPfaL - 1, nhi = bi < kPfaL - 1 ? bi + 1 : 0;
-#pragma unroll
-    for (int side = 0; side < 2; ++side) {
-        const int n = side ? nhi : nlo;
-        if (t == n % kPfaC) {
-            const int j = n / kPfaC;
-            float sel = 0.f;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) sel = q == j ? mag[q] : sel;
-            nbr[side] = sel;
-        }
-    }
+    if (lane == 0) { red_s[wave] = sm; red_d[wave] = s2; red_v[wave] = bv; red_i[wave] = bi; }
     __syncthreads();
     if (t == 0) {
-        d2 = 0.f;
+        double dsm = 0.0, ds2 = 0.0;
+        bv = red_v[0]; bi = red_i[0];
 #pragma unroll
-        for (int w = 0; w < 16; ++w) d2 += red_d[w];
+        for (int w = 0; w < 16; ++w) { dsm += (double)red_s[w]; ds2 += (double)red_d[w]; }
+#pragma unroll
+        for (int w = 1; w < 16; ++w) {
+            const float ov = red_v[w];
+            const int oi = red_i[w];
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        // population variance from the two sums (the squares were summed unscaled)
+        const double mean = dsm / (double)kPfaL;
+        const double var = ds2 / ((double)kPfaL * (double)kPfaL * (double)kPfaL) - mean * mean;
+        const int nlo = bi > 0 ? bi - 1 : kPfaL - 1, nhi = bi < kPfaL - 1 ? bi + 1 : 0;
         DirStats r;
         r.argmax = bi;
         r.peak = bv;
-        r.mean = mean;
-        r.std = sqrtf(d2 * (1.0f / kPfaL));
-        r.lo = nbr[0];
-        r.hi = nbr[1];
+        r.mean = (float)mean;
+        r.std = (float)sqrt(var > 0.0 ? var : 0.0);
+        r.lo = data[(nlo / kPfaC) * kPfaPitch + pfa_sigma(nlo % kPfaC)].x;
+        r.hi = data[(nhi / kPfaC) * kPfaPitch + pfa_sigma(nhi % kPfaC)].x;
         out[cell] = r;
     }
+    __syncthreads();                              // (the neighbours are read: the next cell may write `data`)
     PFA_STAMP(6);
+    cell += MODE == 0 ? (int)gridDim.x : 1;
+    if (cell >= cell_end) break;
+    PFA_STAMP(0);
+    p1();
+    }
 }
 
 // all correlations of `ncell` cells on `stream`, statistics included
 inline void pfa_corr_launch(hipStream_t stream, const float2* x, const int* xsel, const int* rsel,
                             int ncell, float2* RS, DirStats* stats) {
-    hipLaunchKernelGGL(pfa_corr_kernel<0>, dim3(ncell), dim3(kPfaThreads), 0, stream, x,
-                       (const float*)nullptr, xsel, rsel, RS, 0, stats);
+    if (ncell <= 0) return;
+    int dev = 0, n_cu = 256;
+    if (hipGetDevice(&dev) == hipSuccess)
+        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    const int grid = ncell < n_cu ? ncell : n_cu;
+    hipLaunchKernelGGL(pfa_corr_kernel<0>, dim3(grid), dim3(kPfaThreads), 0, stream, x,
+                       (const float*)nullptr, xsel, rsel, RS, 0, ncell, stats);
 }
 
 // spectrum of the replica in slot `slot` (rep_slot0 = table of real replicas [slots][L])
 inline void pfa_replica_launch(hipStream_t stream, const float* rep_slot0, int slot, float2* RS) {
     hipLaunchKernelGGL(pfa_corr_kernel<1>, dim3(1), dim3(kPfaThreads), 0, stream,
                        (const float2*)nullptr, rep_slot0, (const int*)nullptr, (const int*)nullptr, RS,
-                       slot, (DirStats*)nullptr);
+                       slot, 1, (DirStats*)nullptr);
 }
 
 }  // namespace gpsmi
