@@ -127,6 +127,7 @@ __device__ inline double fit_code_phase(double lo, double pk, double hi, int mx)
 #include "gpsmi_trk_general.h"
 #pragma clang fp contract(off)
 #include "gpsmi_trk_span.h"
+#include "gpsmi_trk_span8.h"
 
 namespace gpsmi {
 
@@ -457,6 +458,7 @@ struct gpsmi_trk {
     float2* d_twN = nullptr; float2* d_RS = nullptr; float2* d_S = nullptr;
     bool pfa = false;                // ... or natively in LDS at 16368 samples (gpsmi_pfa.h)
     float2* d_RSp = nullptr;
+    bool span8 = false;              // the matrix-pipe correlator for CS = 16368, N_CYC = 8 (gpsmi_trk_span8.h)
     TrkParams P;
 };
 
@@ -486,7 +488,12 @@ static int trk_reserve(gpsmi_trk* h, size_t njobs) {
         GPSMI_HIP(hipMalloc((void**)&h->d_xsel, njobs * sizeof(int)));
         GPSMI_HIP(hipMalloc((void**)&h->d_rsel, njobs * sizeof(int)));
     }
-    if (h->nchunks > 1)
+    if (h->span8) {         // one 2 KiB record per range of every (block, channel group)
+        const size_t units = ((njobs + h->max_ch - 1) / h->max_ch) * ((h->max_ch + kSpCh - 1) / kSpCh);
+        for (auto& sl : h->slot)
+            GPSMI_HIP(hipMalloc((void**)&sl.d_rec, units * kS8Ranges * kS8RecFloats * sizeof(float)));
+    }
+    if (h->nchunks > 1 && !h->span8)
         GPSMI_HIP(hipMalloc((void**)&h->d_partial_g,
                             njobs * h->nchunks * (h->cfg.n_cyc + 1) * sizeof(float2)));
     GPSMI_HIP(hipMalloc((void**)&h->d_tab_in, njobs * sizeof(gpsmi_trk_state)));
@@ -614,6 +621,13 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
         else
             hipLaunchKernelGGL(trk_stream_mfma_kernel<4>, mgrid, dim3(256), 0, h->stream, d_iq,
                                sl.d_mid, h->d_code2, P, ng12, nblocks, sl.d_partial);
+    } else if (h->span8) {                 // CS = 16368, N_CYC = 8 on the matrix pipe
+        const int ng12 = (nch + kSpCh - 1) / kSpCh;
+        const int nwaves = nblocks * ng12 * kS8Ranges;
+        hipLaunchKernelGGL(trk_span8_kernel, dim3((nwaves + 3) / 4), dim3(256), 0, h->stream, d_iq,
+                           sl.d_mid, h->d_code_eo, P, ng12, nblocks, sl.d_rec);
+        hipLaunchKernelGGL(trk_span8_collect_kernel, dim3(njobs), dim3(64), 0, h->stream, sl.d_rec,
+                           sl.d_mid, P, ng12, njobs, sl.d_partial);
     } else {                               // the vector correlator (other block / code lengths)
         const dim3 grid(sgrid.x, h->nchunks), block(kStreamThreads);
         float2* pdst = h->nchunks > 1 ? h->d_partial_g : sl.d_partial;
@@ -798,6 +812,15 @@ static int trk_build(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk* h) {
         GPSMI_HIP(hipMalloc((void**)&h->d_RSp, b));
         GPSMI_HIP(hipMemset(h->d_RSp, 0, b));                // slot 0: closed channels
     }
+    {
+        const char* mf = getenv("GPSMI_STREAM_MFMA");        // =0 keeps the vector correlator
+        h->span8 = h->general && cfg->code_samples == kS8Cs && cfg->n_cyc == kS8Rows && !(mf && atoi(mf) == 0);
+        if (h->span8) {
+            const size_t b2 = (size_t)(GPSMI_MAX_PRN + 1) * 2 * kS8Cs * sizeof(float);
+            GPSMI_HIP(hipMalloc((void**)&h->d_code_eo, b2));
+            GPSMI_HIP(hipMemset(h->d_code_eo, 0, b2));
+        }
+    }
     if (h->big) {
         std::vector<float2> twn(kBigN);
         for (int k = 0; k < kBigN; ++k) {
@@ -889,6 +912,13 @@ int gpsmi_trk_set_replica(gpsmi_trk* h, int prn, const float* replica, const flo
         for (int e = 0; e < 2; ++e)
             for (int i = 0; i < kFftN; ++i) eo[e * kFftN + i] = replica[2 * (i % (kFftN / 2)) + e];
         GPSMI_HIP(hipMemcpy(h->d_code_eo + (size_t)prn * 2 * kFftN, eo.data(), eo.size() * sizeof(float),
+                            hipMemcpyHostToDevice));
+    }
+    if (h->span8) {                        // plane e, entry s = replica[2 (s mod cs / 2) + e], each plane twice
+        std::vector<float> eo(2 * cs);
+        for (int e = 0; e < 2; ++e)
+            for (size_t i = 0; i < cs; ++i) eo[e * cs + i] = replica[2 * (i % (cs / 2)) + e];
+        GPSMI_HIP(hipMemcpy(h->d_code_eo + (size_t)prn * 2 * cs, eo.data(), eo.size() * sizeof(float),
                             hipMemcpyHostToDevice));
     }
     if (!h->general)                       // the other path needs no 2048-point spectrum
