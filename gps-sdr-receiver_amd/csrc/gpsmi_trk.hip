@@ -363,6 +363,30 @@ __global__ __launch_bounds__(256) void trk_epilogue_span_kernel(
     epilogue_job(s_si, st_out[job], md.delay_used, s_S, P, out[job], lane, s_mag, s_dev, s_real, s_df);
 }
 
+// One wave per job (four jobs per workgroup) behind trk_span8_kernel: the wave adds up the 11 range
+// records of its job (span8_collect) and runs the per-job part on the windows: no separate collect
+// launch, no round trip of the window sums through memory.
+__global__ __launch_bounds__(256) void trk_epilogue_span8_kernel(
+    const gpsmi_trk_state* __restrict__ st_in, gpsmi_trk_state* __restrict__ st_out,
+    const JobMid* __restrict__ mid, const float* __restrict__ rec, int ngroups, TrkParams P, int njobs,
+    gpsmi_trk_out* __restrict__ out) {
+    __shared__ float s_mag[4][40], s_dev[4][40], s_real[4][40], s_df[4][GPSMI_MAX_DF];
+    __shared__ float s_hi[4][16], s_lo[4][16];
+    __shared__ float2 s_S[4][GPSMI_MAX_DUMPS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int job = blockIdx.x * 4 + wave;
+    if (job >= njobs) return;
+    const JobMid md = mid[job];
+    if (!md.active) {
+        epilogue_closed(st_in[job], st_out[job], out[job], st_out != st_in, lane);
+        return;
+    }
+    span8_collect(rec, ngroups, job / P.nch, job % P.nch, md.delay_used, md.om, lane, s_hi[wave], s_lo[wave],
+                  s_S[wave]);
+    epilogue_job(st_in[job], st_out[job], md.delay_used, s_S[wave], P, out[job], lane, s_mag[wave], s_dev[wave],
+                 s_real[wave], s_df[wave]);
+}
+
 }  // namespace gpsmi
 
 namespace gpsmi {
@@ -626,8 +650,6 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
         const int nwaves = nblocks * ng12 * kS8Ranges;
         hipLaunchKernelGGL(trk_span8_kernel, dim3((nwaves + 3) / 4), dim3(256), 0, h->stream, d_iq,
                            sl.d_mid, h->d_code_eo, P, ng12, nblocks, sl.d_rec);
-        hipLaunchKernelGGL(trk_span8_collect_kernel, dim3(njobs), dim3(64), 0, h->stream, sl.d_rec,
-                           sl.d_mid, P, ng12, njobs, sl.d_partial);
     } else {                               // the vector correlator (other block / code lengths)
         const dim3 grid(sgrid.x, h->nchunks), block(kStreamThreads);
         float2* pdst = h->nchunks > 1 ? h->d_partial_g : sl.d_partial;
@@ -661,7 +683,10 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
         h->main_tail = sl.corr_done;          // (gpsmi_acq_after_trk orders the search behind this one)
         GPSMI_HIP(hipStreamWaitEvent(es, sl.corr_done, 0));
     }
-    if (span_single)
+    if (h->span8)
+        hipLaunchKernelGGL(trk_epilogue_span8_kernel, dim3((njobs + 3) / 4), dim3(256), 0, es, st_in,
+                           st_out, sl.d_mid, sl.d_rec, ng_span, P, njobs, sl.d_out);
+    else if (span_single)
         hipLaunchKernelGGL(trk_epilogue_span_kernel, dim3(njobs), dim3(256), 0, es, st_in, st_out,
                            sl.d_mid, sl.d_rec, ng_span, P, njobs, sl.d_out);
     else

@@ -20,10 +20,13 @@
 //   A lane holds ONE real number of B per pair -- component kappa at parity pi for its channel --
 //   for two consecutive pairs in a packed register, advanced four positions at a time by the
 //   coupled recurrence dl -= k u, u += dl (k = 4 sin^2(2 phi)), re-seeded with the exact phasor
-//   every fourth tile; the sign of A's (re, im) entries is one packed multiply per two pairs.
+//   every fourth tile (one step behind the tile start, so every step advances first and uses then);
+//   the sign of A's (re, im) entries is one packed multiply per two pairs.
 //
-// Order of the float32 sums = a property of the data: a block is cut into 11 RANGES of 1488
-// positions (31 tiles of 48: 16368 = 11 * 31 * 48); a range is summed position by position (two
+// Order of the float32 sums = a property of the data: a block is cut into 31 RANGES of 528
+// positions (11 tiles of 48: 16368 = 31 * 11 * 48; with 11 ranges of 31 tiles a 512-block batch is
+// 22 waves per CU against the 16 the registers admit, a round and a third: 0.150 ms, with 31 ranges
+// it is 62 waves in just under four rounds: 0.143 ms); a range is summed position by position (two
 // interleaved accumulators: even and odd pairs) by one wave, which writes its raw sums
 // (`tot`, and `lo_fin` = what lay below the delay when the boundary fell inside the range);
 // trk_span8_collect_kernel adds the ranges of a block in ascending order and forms the windows.
@@ -37,7 +40,7 @@ namespace gpsmi {
 
 constexpr int kS8Cs = 16368, kS8Rows = 8;
 constexpr int kS8Tile = 48;                          // positions per tile: 384 contiguous bytes per row
-constexpr int kS8TilesPerRange = 31, kS8Ranges = 11; // 11 * 31 * 48 = 16368
+constexpr int kS8TilesPerRange = 11, kS8Ranges = 31; // 31 * 11 * 48 = 16368
 constexpr int kS8RangeLen = kS8Tile * kS8TilesPerRange;
 constexpr int kS8RowDw = 2 * kS8Tile + 4;            // dwords per tile row (100: lane = (row, k) reads hit 32 banks)
 constexpr int kS8TileFloats = kS8Rows * kS8RowDw;
@@ -143,8 +146,10 @@ __global__ __launch_bounds__(256) void trk_span8_kernel(
     const sp2 nk = sp2{-4.0f * sh * sh, -4.0f * sh * sh};               // -4 sin^2(2 phi): a step of four positions
     const float2 omw4 = make_float2(2.0f * sh * sh, -2.0f * sh * chh);  // 1 - exp(+j 4 phi)
     sp2 u2, dl2;
+    // (seeded one step -- four positions -- BEHIND the tile start: every step of the loop advances
+    // first and uses then, the first one included)
     auto seed = [&](int m0) {
-        const float2 z0 = sp_phasor_rev(fmaf(f_eff, (float)(m0 + pi + 1) * inv_fs, ph_rev));
+        const float2 z0 = sp_phasor_rev(fmaf(f_eff, (float)(m0 - 4 + pi + 1) * inv_fs, ph_rev));
         const float2 z1 = sp_cmul(z0, w2);
         const float2 dz0 = sp_cmul(z0, omw4), dz1 = sp_cmul(z1, omw4);  // z(m) - z(m - 4)
         const float a0 = kap ? z0.y : z0.x, a1 = kap ? z1.y : z1.x;
@@ -172,43 +177,68 @@ __global__ __launch_bounds__(256) void trk_span8_kernel(
         __builtin_amdgcn_sched_barrier(0);
         if (tix % kS8Reseed == 0) seed(pos0 + tix * kS8Tile);
         const int step0 = tix * (kS8Tile / 4);                          // first step of the tile
+        constexpr int kSteps = kS8Tile / 4;                             // two pairs = four positions per step
+        if (nbs < step0 || nbs >= step0 + kSteps) {
+            // ---- no window boundary in this tile (30 of 31 tiles at least): straight-line code, every
+            // LDS read of the tile requested before the first MFMA
+            // (a third of a tile at a time: 16 registers of operands, six waves per SIMD; the reads are
+            // pinned above the arithmetic, hipcc otherwise sinks each to its use and waits there)
+            constexpr int kChunk = 4;
 #pragma unroll
-        for (int s = 0; s < kS8Tile / 4; ++s) {                         // two pairs = four positions per step
-            sp2 a2 = sp2{ap[8 * s], ap[8 * s + 4]};
-            const sp2 c2 = *reinterpret_cast<const sp2*>(cp + 2 * s);
-            a2 = a2 * a_sign;
-            if (!(tix % kS8Reseed == 0 && s == 0)) {                    // (a fresh seed is used as it is)
+            for (int h2 = 0; h2 < kSteps / kChunk; ++h2) {
+                sp2 a2[kChunk], c2[kChunk];
+#pragma unroll
+                for (int s = 0; s < kChunk; ++s) {
+                    a2[s] = sp2{ap[8 * (s + kChunk * h2)], ap[8 * (s + kChunk * h2) + 4]};
+                    c2[s] = *reinterpret_cast<const sp2*>(cp + 2 * (s + kChunk * h2));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < kChunk; ++s) {
+                    dl2 = __builtin_elementwise_fma(nk, u2, dl2);
+                    u2 = u2 + dl2;
+                    const sp2 av = a2[s] * a_sign, b2 = c2[s] * u2;
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b2.x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b2.y, acc1, 0, 0, 0);
+                }
+            }
+        } else {
+            // ---- some channel's window boundary lies in this tile: the lanes of that channel close
+            // their lo sum where it passes; a pair that straddles an odd boundary is issued twice
+            // with B masked
+#pragma unroll 1
+            for (int s = 0; s < kSteps; ++s) {
+                sp2 a2 = sp2{ap[8 * s], ap[8 * s + 4]};
+                const sp2 c2 = *reinterpret_cast<const sp2*>(cp + 2 * s);
+                a2 = a2 * a_sign;
                 dl2 = __builtin_elementwise_fma(nk, u2, dl2);
                 u2 = u2 + dl2;
-            }
-            sp2 b2 = c2 * u2;
-            if (step0 + s == nbs) {
-                // some channel's window boundary lies in these four positions: the lanes of that
-                // channel close their lo sum where it passes; a pair that straddles an odd boundary is
-                // issued twice with B masked
-                const int Pq = 4 * (step0 + s);                        // relative position of the step
+                const sp2 b2 = c2 * u2;
+                if (step0 + s == nbs) {
+                    const int Pq = 4 * (step0 + s);                    // relative position of the step
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int Pi = Pq + 2 * i;
-                    float bv = i ? b2.y : b2.x;
-                    const float av = i ? a2.y : a2.x;
-                    if (pb == Pi) close_lo();
-                    const bool odd = pb == Pi + 1;
-                    if (__builtin_amdgcn_ballot_w64(odd) != 0) {
-                        const float b_first = odd ? (pi == 0 ? bv : 0.f) : bv;
-                        if (i) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b_first, acc1, 0, 0, 0);
-                        else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b_first, acc0, 0, 0, 0);
-                        if (odd) close_lo();
-                        bv = odd ? (pi == 1 ? bv : 0.f) : 0.f;          // then position P + 1 of those lanes
+                    for (int i = 0; i < 2; ++i) {
+                        const int Pi = Pq + 2 * i;
+                        float bv = i ? b2.y : b2.x;
+                        const float av = i ? a2.y : a2.x;
+                        if (pb == Pi) close_lo();
+                        const bool odd = pb == Pi + 1;
+                        if (__builtin_amdgcn_ballot_w64(odd) != 0) {
+                            const float b_first = odd ? (pi == 0 ? bv : 0.f) : bv;
+                            if (i) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b_first, acc1, 0, 0, 0);
+                            else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b_first, acc0, 0, 0, 0);
+                            if (odd) close_lo();
+                            bv = odd ? (pi == 1 ? bv : 0.f) : 0.f;      // then position P + 1 of those lanes
+                        }
+                        if (i) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc1, 0, 0, 0);
+                        else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc0, 0, 0, 0);
                     }
-                    if (i) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc1, 0, 0, 0);
-                    else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc0, 0, 0, 0);
+                    if (pb >= Pq && pb < Pq + 4) pb = kSpInf;           // this lane's boundary is behind it
+                    nbs = sp_wave_min(pb == kSpInf ? kSpInf : pb >> 2);
+                } else {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, b2.x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, b2.y, acc1, 0, 0, 0);
                 }
-                if (pb >= Pq && pb < Pq + 4) pb = kSpInf;               // this lane's boundary is behind it
-                nbs = sp_wave_min(pb == kSpInf ? kSpInf : pb >> 2);
-            } else {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, b2.x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, b2.y, acc1, 0, 0, 0);
             }
         }
     }
@@ -222,18 +252,12 @@ __global__ __launch_bounds__(256) void trk_span8_kernel(
     }
 }
 
-// One wave per job: the ranges of the block in ascending order -> hi / lo row sums -> the windows,
-// partial[job][q + 1] = U[q] hi[q] + U[q+1] lo[q+1], q = -1 .. 7 (what the other correlators write).
-__global__ __launch_bounds__(64) void trk_span8_collect_kernel(
-    const float* __restrict__ rec, const JobMid* __restrict__ mid, TrkParams P, int ngroups, int njobs,
-    float2* __restrict__ partial) {
-    __shared__ float s_hi[16], s_lo[16];
-    const int job = blockIdx.x, lane = threadIdx.x;
-    if (job >= njobs) return;
-    const JobMid md = mid[job];
-    if (!md.active) return;
-    const int b = job / P.nch, cidx = job % P.nch, g = cidx / kSpCh, c = cidx % kSpCh;
-    const int d = md.delay_used;
+// One wave: the ranges of a job's block in ascending order -> hi / lo row sums -> the windows
+// S[q + 1] = U[q] hi[q] + U[q+1] lo[q+1], q = -1 .. 7 (what the other correlators write to
+// partial[job][.]).  s_hi / s_lo: 16 floats of LDS each, S: 9 entries.
+__device__ __forceinline__ void span8_collect(const float* __restrict__ rec, int ngroups, int b, int cidx,
+                                              int d, float om, int lane, float* s_hi, float* s_lo, float2* S) {
+    const int g = cidx / kSpCh, c = cidx % kSpCh;
     if (lane < 16) {                                      // lane = row of M = (code period, component)
         const int src_lane = (lane >> 2) * 16 + c, v = lane & 3;
         const float* base = rec + ((size_t)(b * ngroups + g) * kS8Ranges) * kS8RecFloats + src_lane;
@@ -254,14 +278,13 @@ __global__ __launch_bounds__(64) void trk_span8_collect_kernel(
         s_lo[lane] = lo;
     }
     __builtin_amdgcn_wave_barrier();
-    __syncthreads();
     if (lane <= kS8Rows) {
         const int q = lane - 1;
         const float hx = q >= 0 ? s_hi[2 * q] : 0.f, hy = q >= 0 ? s_hi[2 * q + 1] : 0.f;
         const float lx = q + 1 < kS8Rows ? s_lo[2 * (q + 1)] : 0.f, ly = q + 1 < kS8Rows ? s_lo[2 * (q + 1) + 1] : 0.f;
-        partial[(size_t)job * (kS8Rows + 1) + lane] =
-            sp_window(hx, hy, lx, ly, sp_row_factor(md.om, q), sp_row_factor(md.om, q + 1));
+        S[lane] = sp_window(hx, hy, lx, ly, sp_row_factor(om, q), sp_row_factor(om, q + 1));
     }
+    __builtin_amdgcn_wave_barrier();
 }
 
 }  // namespace gpsmi
