@@ -198,13 +198,12 @@ __global__ __launch_bounds__(kPfaThreads) void pfa_corr_kernel(
     __shared__ __attribute__((aligned(16))) fft_c data[16 * kPfaPitch];
     __shared__ float red_s[16], red_v[16], red_d[16];
     __shared__ int red_i[16];
-    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int t = threadIdx.x;
     // MODE 0: the workgroups are persistent (one per CU: the LDS image admits no second one) and
     // take every gridDim-th cell; the samples of the next cell are requested before the statistics
     // of the current one, so only a workgroup's first cell waits for memory at its start
     int cell = MODE == 0 ? cell0 + (int)blockIdx.x : cell0;
     const int cell_end = MODE == 0 ? cell0 + ncell : cell0 + 1;
-    const int sig = pfa_sigma(t < kPfaC ? t : 0);
     __shared__ fft_c tw16[16];                    // exp(+2 pi i m / 16)
     __shared__ fft_c trig31[31];                  // (cos, sin)(2 pi m / 31) for P3's split lines
     if (t < 16) tw16[t] = pfa_w16(t, false);
@@ -226,7 +225,6 @@ __global__ __launch_bounds__(kPfaThreads) void pfa_corr_kernel(
             const int voff = (t < kPfaC ? t : kPfaL) * (int)sizeof(float2);
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                typedef float pfa_f2 __attribute__((ext_vector_type(2)));
                 nx[j] = __builtin_bit_cast(fft_c, __builtin_amdgcn_raw_buffer_load_b64(
                     rs, voff, j * kPfaC * (int)sizeof(float2), 0));
             }

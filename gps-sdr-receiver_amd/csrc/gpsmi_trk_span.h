@@ -198,11 +198,20 @@ __device__ __forceinline__ void sp_load_tile(const void* blk, int pos, int lane,
 template <int FMT>
 __device__ __forceinline__ void sp_store_tile(float* tl, int lane, const sp4 (&st)[16]) {
     if (FMT == 0) {
+        // rows are 8-byte aligned (pitch 130 dwords, which the transposed reads need): two b64 writes
+        // per 16-byte piece.  Lanes c and c + 8 of a 16-lane store group would meet on one bank (their
+        // pieces are 32 and 64 dwords apart: measured, tools/probe/lds_conflict_probe.hip, conflict /
+        // active = 0.50) -- so the pieces with bit 3 of their index set keep their two samples in
+        // SWAPPED order in LDS: each store instruction then covers all 32 banks once.  sp_tile_swz()
+        // tells the readers.
+        const int swz = ((lane & 31) >> 3) & 1;
         float* st_dst = tl + (lane >> 5) * kSpRowDw + 4 * (lane & 31);
+        float* d0 = st_dst + 2 * swz;                  // where the piece's first sample goes
+        float* d1 = st_dst + 2 * (1 - swz);            // ... and its second
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {                 // rows are 8-byte aligned: two b64 writes
-            *reinterpret_cast<sp2*>(st_dst + i * 2 * kSpRowDw) = sp2{st[i].x, st[i].y};
-            *reinterpret_cast<sp2*>(st_dst + i * 2 * kSpRowDw + 2) = sp2{st[i].z, st[i].w};
+        for (int i = 0; i < 16; ++i) {
+            *reinterpret_cast<sp2*>(d0 + i * 2 * kSpRowDw) = sp2{st[i].x, st[i].y};
+            *reinterpret_cast<sp2*>(d1 + i * 2 * kSpRowDw) = sp2{st[i].z, st[i].w};
         }
     } else {
         float* st_dst = tl + (lane >> 3) * kSpRowDw + 16 * (lane & 7);
@@ -348,6 +357,9 @@ __device__ __forceinline__ void span_wave(const void* __restrict__ blk, const vo
     int nb = next_boundary(rel0);        // (a boundary AT the range start needs no action: all hi)
     const float* ap0 = tl + (lane & 15) * kSpRowDw + k;              // lane = (row, k), rows 0 .. 15
     const float* ap1 = ap0 + 16 * kSpRowDw;                          // rows 16 .. 31
+    // pairs 8 .. 15 and 24 .. 31 of a complex64 tile sit with their two positions swapped in LDS
+    // (sp_store_tile): the lane of parity pi reads the other half there, k ^ 2
+    const int swz_ofs = FMT == 0 ? (2 - 4 * pi) : 0;                 // (k ^ 2) - k
 
 #pragma unroll 1
     for (int tix = 0; tix < kTiles; ++tix) {
@@ -371,8 +383,11 @@ __device__ __forceinline__ void span_wave(const void* __restrict__ blk, const vo
         struct Ops { sp4 a0, a1, c0, c1; };
         auto read_ops = [&](int q4) {                                // q4: pair index in the tile, multiple of 4
             Ops o;
-            o.a0 = sp4{ap0[4 * q4], ap0[4 * q4 + 4], ap0[4 * q4 + 8], ap0[4 * q4 + 12]};
-            o.a1 = sp4{ap1[4 * q4], ap1[4 * q4 + 4], ap1[4 * q4 + 8], ap1[4 * q4 + 12]};
+            const int sw = ((q4 >> 3) & 1) ? swz_ofs : 0;            // (four pairs never straddle a multiple of 8)
+            const float* a0p = ap0 + sw;
+            const float* a1p = ap1 + sw;
+            o.a0 = sp4{a0p[4 * q4], a0p[4 * q4 + 4], a0p[4 * q4 + 8], a0p[4 * q4 + 12]};
+            o.a1 = sp4{a1p[4 * q4], a1p[4 * q4 + 4], a1p[4 * q4 + 8], a1p[4 * q4 + 12]};
             o.c0 = *reinterpret_cast<const sp4*>(crow[0] + (q4 & 15));
             o.c1 = *reinterpret_cast<const sp4*>(crow[1] + (q4 & 15));
             return o;
