@@ -94,7 +94,7 @@ int main() {
         hipLaunchKernelGGL(k_span, dim3(32), dim3(64), 0, 0, mid, (const int4*)blk, rec);
         hipLaunchKernelGGL(k_epi, dim3(12), dim3(256), 0, 0, mid, state, rec, out);
     });
-    timed("one kernel with all seven dependent trips (a fused block, no hand-over cost counted)", [&] {
+    timed("the first of them alone (three dependent trips): what a launch with its trips costs", [&] {
         hipLaunchKernelGGL(k_corr, dim3(12), dim3(256), 0, 0, state, blk, rep, mid);
     });
     return 0;

@@ -39,6 +39,7 @@ fi
 if [ $part = rest ] || [ $part = all ]; then
 tools/probe/span_prof 1024 > $out/span_prof.txt 2>&1 || echo "span_prof failed"
 tools/probe/pfa_prof 6144 > $out/pfa_prof.txt 2>&1 || echo "pfa_prof failed"
+tools/probe/chain_floor > $out/chain_floor.txt 2>&1 || echo "chain_floor failed"
 python3 tools/kernel_bench.py > $out/kernel_bench.txt 2>&1
 python3 tools/kernel_bench.py --delays aligned >> $out/kernel_bench.txt 2>&1
 python3 tools/kernel_bench.py --code-samples 16368 --n-cyc 8 --blocks 512 --iters 5 >> $out/kernel_bench.txt 2>&1
