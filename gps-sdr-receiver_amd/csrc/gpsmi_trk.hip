@@ -1328,20 +1328,31 @@ int gpsmi_trk_set_streams(gpsmi_trk* h, int n_streams) {
     if (rc) return rc;
     const size_t rows = (size_t)n_streams * h->max_ch;
     const size_t ngps = (size_t)h->cfg.n_cyc * h->cfg.code_samples;
-    if (h->d_state) GPSMI_HIP(hipFree(h->d_state));
-    h->d_state = nullptr;
-    if (h->d_block) GPSMI_HIP(hipFree(h->d_block));
-    h->d_block = nullptr;
-    h->n_streams = 1;                      // (a failure below leaves a consistent one-stream handle...
-    h->h_state.assign(h->max_ch, gpsmi_trk_state{});
-    h->state_dirty_host = false;
-    GPSMI_HIP(hipMalloc((void**)&h->d_state, rows * sizeof(gpsmi_trk_state)));   // ... whose buffers are at least this big)
-    GPSMI_HIP(hipMemset(h->d_state, 0, rows * sizeof(gpsmi_trk_state)));
-    GPSMI_HIP(hipMalloc((void**)&h->d_block, (size_t)n_streams * ngps * sizeof(float2)));
+    // new buffers first, then the swap: a failed allocation leaves the handle as it was
+    gpsmi_trk_state* d_state = nullptr;
+    float2* d_block = nullptr;
+    if (hipMalloc((void**)&d_state, rows * sizeof(gpsmi_trk_state)) != hipSuccess ||
+        hipMalloc((void**)&d_block, (size_t)n_streams * ngps * sizeof(float2)) != hipSuccess) {
+        if (d_state) (void)hipFree(d_state);
+        (void)hipGetLastError();
+        return fail(GPSMI_E_NOMEM, "out of device memory for %d streams", n_streams);
+    }
+    rc = hipMemset(d_state, 0, rows * sizeof(gpsmi_trk_state)) == hipSuccess ? trk_reserve(h, rows)
+                                                                              : fail(GPSMI_E_HIP, "hipMemset of the state rows failed");
+    if (rc) {
+        (void)hipFree(d_state);
+        (void)hipFree(d_block);
+        return rc;
+    }
+    if (h->d_state) (void)hipFree(h->d_state);
+    if (h->d_block) (void)hipFree(h->d_block);
+    h->d_state = d_state;
+    h->d_block = d_block;
     h->h_state.assign(rows, gpsmi_trk_state{});
+    h->state_dirty_host = false;
     h->n_streams = n_streams;
     h->replay_nb = 0;
-    return trk_reserve(h, rows);
+    return GPSMI_OK;
 }
 
 int gpsmi_trk_set_timing(gpsmi_trk* h, int on) {

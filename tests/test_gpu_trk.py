@@ -602,6 +602,25 @@ def test_time_domain_correlation_variant_agrees(closed_loop_hirate, golden_hirat
         assert np.array_equal(r[1][k], fft[k]), k
 
 
+@pytest.mark.parametrize('env', [{'GPSMI_STREAM_MFMA': '0'}, {'GPSMI_DIRECT_CORR': '2'}])
+def test_hirate_fallback_kernels_agree(closed_loop_hirate, golden_hirate, monkeypatch, env):
+    """The kernels other code lengths still run, selected at 16368 samples: GPSMI_STREAM_MFMA=0 the
+    chunked vector correlator instead of the matrix one, GPSMI_DIRECT_CORR=2 the zero-padded
+    32768-point FFT pair instead of the native-length correlation.  Same reference fixture, same
+    integer results as the default path."""
+    from gpsmi.engine import Config
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    r = _run_closed_loop(golden_hirate, 'hirate', Config(code_samples=16368, n_cyc=8))
+    for k in env:
+        monkeypatch.delenv(k)
+    r[0].close()
+    _check_closed_loop(r[1], golden_hirate)
+    ref = closed_loop_hirate[1]
+    for k in ('mx', 'delay', 'delay_used', 'n_dumps', 'nps', 'phase_locked'):
+        assert np.array_equal(r[1][k], ref[k]), k
+
+
 def test_result_slots_carry_nothing_over(closed_loop):
     """The result buffers are not cleared between launches: every byte of an open
     channel's record is rewritten and a closed channel's record is zeroed by the

@@ -11,7 +11,9 @@ for r in csv.DictReader(open(f)):
     name = r['Kernel_Name'].split('(')[0].replace('void ', '').replace('gpsmi::', '')
     rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), name, int(r['Grid_Size_X']) // int(r['Workgroup_Size_X'])))
 rows.sort()
-corrs = [i for i, r in enumerate(rows) if r[2].startswith('trk_corr_kernel<4') and r[3] > 1000]
+# the batch launches of the complex64 headline step (the raw-u8 leg runs <4, 1>); the timed steps are
+# the last of them
+corrs = [i for i, r in enumerate(rows) if r[2].startswith('trk_corr_kernel<4, 0>') and r[3] > 1000]
 i0 = corrs[-(nsteps + 3)]
 t0 = rows[i0][0]
 for s, e, n, g in rows[i0:]:
