@@ -266,6 +266,49 @@ def test_channel_management_and_errors():
     eng.close()
 
 
+def test_streams_and_streaming_errors_and_fallbacks(golden_default):
+    """Edges of the round-3 entry points: stream counts out of range, replay on a multi-stream
+    handle, ragged multi-stream input, set_streams resets the channels, and
+    gpsmi_trk_process_stream from PAGEABLE memory (no kernel may read that: the runtime's copy is
+    taken instead) and with batched streams, against the blocking call."""
+    import ctypes as C
+    from gpsmi.engine import TrkEngine, EngineError, STATE_DTYPE, OUT_DTYPE, check
+    g = golden_default
+    eng = TrkEngine(max_ch=4)
+    for bad in (0, -1, 70000):
+        with pytest.raises(EngineError):
+            check(eng.lib.gpsmi_trk_set_streams(eng.h, bad), 'set_streams')
+    eng.open(0, 5, 0.0, 3)
+    check(eng.lib.gpsmi_trk_set_streams(eng.h, 3), 'set_streams')
+    eng.streams = 3
+    assert all(eng.get_state(c, stream=r)['prn'] == 0 for r in range(3) for c in range(4))
+    with pytest.raises(EngineError):
+        eng.process(np.zeros((2, 65536), np.complex64))          # one block short
+    with pytest.raises(EngineError):
+        eng.replay_load(2, np.zeros((2, 4), dtype=STATE_DTYPE))   # replay keeps to one stream
+    with pytest.raises(ValueError):
+        eng.open(0, 5, 0.0, 0, stream=3)
+    eng.close()
+    # pageable input and batched streams through the streaming call
+    blocks = scene_blocks('default', 5, 8)
+    R, nch = 2, 3
+    ref, got = TrkEngine(max_ch=nch, streams=R), TrkEngine(max_ch=nch, streams=R)
+    for e in (ref, got):
+        for r in range(R):
+            for c, (sv, f0, d0) in enumerate(g['trk_init'][:nch]):
+                e.open(c, int(sv), float(f0), int(d0), stream=r)
+    outs = []
+    for i in range(3):
+        slab = np.ascontiguousarray(np.stack([blocks[2 * i], blocks[2 * i + 1]]))   # ordinary numpy memory
+        want = ref.process(slab)
+        o = np.zeros((R, nch), dtype=OUT_DTYPE)
+        got.process_stream(slab, o)
+        got.wait()                                      # (pageable source and sink: wait per block)
+        assert o.tobytes() == want.tobytes(), i
+    ref.close()
+    got.close()
+
+
 def test_round1_matrix_correlator_agrees(closed_loop, monkeypatch):
     """GPSMI_STREAM_MFMA=3: the round-1 correlator (v_mfma_f32_32x32x2_f32, four waves x 512
     positions per workgroup, gpsmi_trk_stream_mfma.h) computes the same windows as the span
