@@ -98,6 +98,13 @@ __device__ __forceinline__ fft_c pfa_w16(int m, bool minus) {
     return fft_c{cs[m & 15], minus ? -sn[m & 15] : sn[m & 15]};
 }
 
+// a constant operand for the packed multiplies, made on the spot: without this hipcc keeps the nine
+// twiddle pairs of pfa_fft16 in registers across the whole persistent loop (and spills them)
+__device__ __forceinline__ fft_c pfa_fresh(fft_c w) {
+    asm volatile("" : "+v"(w));
+    return w;
+}
+
 // 16-point DFT in registers, natural order in and out, kernel exp(-2 pi i j k / 16):
 // 4 x 4 Cooley-Tukey (j = 4 a + b, k = ka + 4 kb).
 __device__ __forceinline__ void pfa_fft16(fft_c* v) {
@@ -111,9 +118,9 @@ __device__ __forceinline__ void pfa_fft16(fft_c* v) {
 #pragma unroll
     for (int ka = 0; ka < 4; ++ka) {
         fft_c z0 = y[0][ka];
-        fft_c z1 = ka == 0 ? y[1][0] : cmulp(y[1][ka], pfa_w16(ka, true));
-        fft_c z2 = ka == 0 ? y[2][0] : cmulp(y[2][ka], pfa_w16(2 * ka, true));
-        fft_c z3 = ka == 0 ? y[3][0] : cmulp(y[3][ka], pfa_w16(3 * ka, true));
+        fft_c z1 = ka == 0 ? y[1][0] : cmulp(y[1][ka], pfa_fresh(pfa_w16(ka, true)));
+        fft_c z2 = ka == 0 ? y[2][0] : cmulp(y[2][ka], pfa_fresh(pfa_w16(2 * ka, true)));
+        fft_c z3 = ka == 0 ? y[3][0] : cmulp(y[3][ka], pfa_fresh(pfa_w16(3 * ka, true)));
         dft4p<false>(z0, z1, z2, z3);
         v[ka] = z0; v[ka + 4] = z1; v[ka + 8] = z2; v[ka + 12] = z3;
     }
@@ -217,8 +224,12 @@ __global__ __launch_bounds__(kPfaThreads) void pfa_corr_kernel(
     // (buffer loads: one scalar base per cell, ONE lane offset for the sixteen loads, the row
     // distance in the instruction's scalar offset -- sixteen 64-bit lane addresses would not fit
     // beside the magnitudes the request is issued next to; a lane past the 1023rd reads nothing)
+    // (unconditional: past the last cell the last one is requested again and never used -- under a
+    // condition the sixteen pairs would have to survive the whole loop body for the case that no
+    // request overwrites them, and spill)
     auto request = [&](int c) {
-        if (MODE == 0 && c < cell_end) {
+        if (MODE == 0) {
+            c = c < cell_end ? c : cell_end - 1;
             const int sel = __builtin_amdgcn_readfirstlane(xsel[c]);
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float2*>(x) + (size_t)sel * kPfaL, 0, kPfaL * (int)sizeof(float2), 0x00020000);
