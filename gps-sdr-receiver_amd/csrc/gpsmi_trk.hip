@@ -463,6 +463,7 @@ struct gpsmi_trk {
     int replay_nb = 0;
     bool replay_forced = false;
     int corr_cg = 4;
+    int corr_small1 = 384, corr_small2 = 1536;   // jobs per launch up to which 1 / 2 channels per correlation workgroup
     int done_by_dispatch = 1;          // GPSMI_DONE_BY_DISPATCH=0: an event record behind the correlator instead
     // code_samples != 2048: time-domain correlation + chunked correlator
     bool general = false;
@@ -575,8 +576,10 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
         // channels per correlation workgroup: fewer channels = fewer live accumulators
         // = more workgroups per CU for the barrier-heavy FFT phase (GPSMI_CORR_CG to tune)
         // (a single block, the closed loop, is latency-bound: spread it over more CUs)
-        const int cg = nblocks * ((nch + h->corr_cg - 1) / h->corr_cg) < 64 ? (nblocks * nch <= 64 ? 1 : 2)
-                                                                             : h->corr_cg;
+        // (GPSMI_CORR_SMALL: job counts up to which one / two channels per workgroup are taken; measured
+        // with R batched receivers of 12 channels, tools/batched_bench.py)
+        const int jobs_all = nblocks * nch;
+        const int cg = jobs_all <= h->corr_small1 ? 1 : (jobs_all <= h->corr_small2 ? 2 : h->corr_cg);
         const int ng = (nch + cg - 1) / cg;
         const dim3 cgrid(nblocks < 8 ? nblocks * ng : ((nblocks + 7) / 8) * 8 * ng);
 #define GPSMI_LAUNCH_CORR(CGV)                                                                          \
@@ -875,6 +878,10 @@ static int trk_build(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk* h) {
     const char* cgs = getenv("GPSMI_CORR_CG");
     if (cgs && (atoi(cgs) == 2 || atoi(cgs) == 4 || atoi(cgs) == 6)) h->corr_cg = atoi(cgs);
     if (const char* dd = getenv("GPSMI_DONE_BY_DISPATCH")) h->done_by_dispatch = atoi(dd) != 0;
+    if (const char* cs1 = getenv("GPSMI_CORR_SMALL")) {
+        int a1 = 0, a2 = 0;
+        if (sscanf(cs1, "%d,%d", &a1, &a2) == 2 && a1 >= 0 && a2 >= a1) { h->corr_small1 = a1; h->corr_small2 = a2; }
+    }
     if (const char* sm = getenv("GPSMI_SPAN_SINGLE_MAX")) {
         const int v = atoi(sm);
         if (v >= 1 && v <= kSpanUnitsMax) h->span_single_max = v;
