@@ -1,6 +1,7 @@
 // Circular code correlation at the native code length of BASELINE config 5,
-// L = 16368 = 16 * 3 * 11 * 31 samples (16.368 Msps), one workgroup per correlation,
-// everything between the folded samples and the findCodePhase statistics in LDS.
+// L = 16368 = 16 * 3 * 11 * 31 samples (16.368 Msps): one workgroup works on one correlation at a
+// time (persistent, one workgroup per CU), everything between the folded samples and the
+// findCodePhase statistics in LDS.
 //
 // The reference does abs(ifft(fft(x) * conj(fft(replica)))) with scipy's length-L
 // transforms (src/gpslib.py:1315-1327, src/gpsrecv.py:250-258) and then mean / std /
@@ -23,8 +24,8 @@
 //       replica spectrum (conjugated: the way back runs as a forward transform of the
 //       conjugate, only magnitudes are needed), DFT-31 again.
 //   P4  as P2.   P5  as P1 backwards: exp(+2 pi i c k / 16), FFT-16, |.| / L at lag
-//       n = c + 1023 j, then mean, two-pass population std, first-index argmax and the
-//       two circular neighbours of the peak for all 16368 lags of the workgroup.
+//       n = c + 1023 j, then mean, population std (from the sum and the sum of squares, combined in
+//       double), first-index argmax and the two circular neighbours of the peak for all 16368 lags.
 //
 // The DFTs of prime length p are dense but use the symmetry of the roots: with
 // a_n = x_n + x_(p-n), b_n = x_n - x_(p-n):  X_k, X_(p-k) = (x_0 + sum a_n cos) -/+ i (sum b_n sin),
@@ -194,7 +195,7 @@ __device__ __forceinline__ void pfa_slab33(fft_c* base) {
     }
 }
 
-// MODE 0: one correlation per workgroup.  x: [nvec][L] complex (wiped-off, folded samples),
+// MODE 0: ncell correlations, persistent workgroups.  x: [nvec][L] complex (wiped-off, folded samples),
 //         cell c uses x[xsel[cell0 + c]] and the spectrum RS[rsel[cell0 + c]]; out[cell0 + c].
 // MODE 1: spectrum of the real replica rep[slot][L] into RS[slot] (P3's thread order:
 //         RS[slot][q * 528 + line], q the Z_31 frequency).
@@ -260,8 +261,8 @@ __global__ __launch_bounds__(kPfaThreads) void pfa_corr_kernel(
 #pragma unroll
             for (int k = 1; k < 16; ++k) {
                 data[k * kPfaPitch + sig] = cmulp(nx[k], tw16[(t * k) & 15]);
-                if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (the twiddle reads four at a time:
-            }                                                          //  all fifteen at once cost a spill)
+                if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (the twiddle reads four at a time)
+            }
         }
     };
     request(cell);
