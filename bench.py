@@ -348,7 +348,7 @@ def measure_batched(E, local, iq_at, nb_avail, chans, Rs=(1, 8, 32, 64), max_ste
 def measure_streamed(E, local, raw_blocks, chans, Rs=(1, 8, 32), steps=48):
     """The reference's own shape of the flow (file -> streamData -> ring buffer -> processData,
     gpsrecv.py:153-186, :76-104, :445-548): blocks arrive in (page-locked) host memory and go up
-    inside the timed loop, block k + 1 under the kernels of block k (gpsmi_trk_process_stream),
+    inside the timed loop, the host running ahead of the device (gpsmi_trk_process_stream),
     closed loop, state on the device, nothing read back.  Raw uint16 (2 B/sample over PCIe, the
     decode fused into the kernels) next to complex64 (8 B/sample), R receivers per step."""
     from gpsmi.synth import raw_to_c64
@@ -387,8 +387,8 @@ def measure_streamed(E, local, raw_blocks, chans, Rs=(1, 8, 32), steps=48):
                         'pcie_gb_per_s': round(R * NGPS * bps / best / 1e9, 2),
                         'x_realtime_per_stream': round(NGPS / best / 2.048e6, 1)})
     return {'config': 'streamed from host: closed loop with the H2D copy of every block inside the timed '
-                      'loop (gpsmi_trk_process_stream, pinned memory, upload of block k + 1 under the '
-                      'kernels of block k), 12 channels per receiver, R receivers per step',
+                      'loop (gpsmi_trk_process_stream, pinned memory, no host wait per block), 12 channels '
+                      'per receiver, R receivers per step',
             'runs': res}
 
 

@@ -427,6 +427,8 @@ struct gpsmi_trk {
     hipEvent_t up_done[2] = {nullptr, nullptr}, stage_free[2] = {nullptr, nullptr};
     bool stage_used[2] = {false, false};
     int stage_idx = 0;
+    size_t stream_inline_max = 8u << 20;     // bytes up to which a streamed block is copied on the main stream
+                                             // (GPSMI_STREAM_INLINE_MAX)
     hipEvent_t order = nullptr;          // orders other handles' streams behind this one
     hipEvent_t main_tail = nullptr;      // the event recorded behind the last work on `stream`, if any
     // two result slots: a replay run writes one while the other is still being copied out
@@ -878,6 +880,7 @@ static int trk_build(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk* h) {
     const char* cgs = getenv("GPSMI_CORR_CG");
     if (cgs && (atoi(cgs) == 2 || atoi(cgs) == 4 || atoi(cgs) == 6)) h->corr_cg = atoi(cgs);
     if (const char* dd = getenv("GPSMI_DONE_BY_DISPATCH")) h->done_by_dispatch = atoi(dd) != 0;
+    if (const char* im = getenv("GPSMI_STREAM_INLINE_MAX")) h->stream_inline_max = (size_t)atoll(im);
     if (const char* cs1 = getenv("GPSMI_CORR_SMALL")) {
         int a1 = 0, a2 = 0;
         if (sscanf(cs1, "%d,%d", &a1, &a2) == 2 && a1 >= 0 && a2 >= a1) { h->corr_small1 = a1; h->corr_small2 = a2; }
@@ -1114,14 +1117,11 @@ int gpsmi_trk_process_stream(gpsmi_trk* h, const void* iq, size_t n, gpsmi_trk_o
     }
     const int s = h->stage_idx;
     h->stage_idx ^= 1;
-    // the block goes up on the upload stream as soon as the kernels that read this staging
-    // block two calls ago have finished; the kernels of this call start behind the upload
-    if (h->stage_used[s]) GPSMI_HIP(hipStreamWaitEvent(h->up_stream, h->stage_free[s], 0));
     // page-locked memory is read by a kernel (see stage_copy_kernel); anything else -- pageable
     // memory would fault under a kernel -- goes through the runtime's copy
     bool pinned = false;
+    hipPointerAttribute_t at{};
     if (bytes % 16 == 0 && ((uintptr_t)iq & 15) == 0) {
-        hipPointerAttribute_t at{};
         if (hipPointerGetAttributes(&at, iq) == hipSuccess)
             pinned = at.type == hipMemoryTypeHost && at.devicePointer != nullptr;
         else
@@ -1132,17 +1132,29 @@ int gpsmi_trk_process_stream(gpsmi_trk* h, const void* iq, size_t n, gpsmi_trk_o
             pinned = hipPointerGetAttributes(&at_end, last) == hipSuccess && at_end.type == hipMemoryTypeHost;
             if (!pinned) (void)hipGetLastError();
         }
-        if (pinned) {
-            const size_t n16 = bytes / 16;
-            const unsigned grid = (unsigned)((n16 + 255) / 256 < 512 ? (n16 + 255) / 256 : 512);
-            hipLaunchKernelGGL(stage_copy_kernel, dim3(grid), dim3(256), 0, h->up_stream,
-                               static_cast<stage_u4*>(h->d_stage[s]), static_cast<const stage_u4*>(at.devicePointer), n16);
-        }
     }
-    if (!pinned)
-        GPSMI_HIP(hipMemcpyAsync(h->d_stage[s], iq, bytes, hipMemcpyHostToDevice, h->up_stream));
-    GPSMI_HIP(hipEventRecord(h->up_done[s], h->up_stream));
-    GPSMI_HIP(hipStreamWaitEvent(h->stream, h->up_done[s], 0));
+    // Up to 8 MiB per step (measured: one receiver's 128 KiB to 64 receivers' 8 MiB of raw samples)
+    // the block goes up IN FRONT of its own kernels on the main stream: the two event packets that
+    // order an upload stream against the main one cost ~7 us per step, and a copy kernel beside the
+    // tracking kernels takes from them what it hides (27.7 against 34.6 us per block for one receiver,
+    // 50 against 58 us for eight; equal at 64).  Beyond that it goes up on the upload stream under the
+    // previous step's kernels, as soon as the kernels that read this staging block two calls ago have
+    // finished.  Either way the host never waits.
+    const bool in_line = pinned && bytes <= h->stream_inline_max;
+    hipStream_t us = in_line ? h->stream : h->up_stream;
+    if (!in_line && h->stage_used[s]) GPSMI_HIP(hipStreamWaitEvent(h->up_stream, h->stage_free[s], 0));
+    if (pinned) {
+        const size_t n16 = bytes / 16;
+        const unsigned grid = (unsigned)((n16 + 255) / 256 < 512 ? (n16 + 255) / 256 : 512);
+        hipLaunchKernelGGL(stage_copy_kernel, dim3(grid), dim3(256), 0, us,
+                           static_cast<stage_u4*>(h->d_stage[s]), static_cast<const stage_u4*>(at.devicePointer), n16);
+    } else {
+        GPSMI_HIP(hipMemcpyAsync(h->d_stage[s], iq, bytes, hipMemcpyHostToDevice, us));
+    }
+    if (!in_line) {
+        GPSMI_HIP(hipEventRecord(h->up_done[s], h->up_stream));
+        GPSMI_HIP(hipStreamWaitEvent(h->stream, h->up_done[s], 0));
+    }
     gpsmi_trk::Slot& sl = h->slot[0];
     h->cur = 0;
     const bool timing = h->timing;
@@ -1150,8 +1162,12 @@ int gpsmi_trk_process_stream(gpsmi_trk* h, const void* iq, size_t n, gpsmi_trk_o
     rc = trk_launch(h, sl, h->d_stage[s], h->d_state, h->d_state, nullptr, h->rows(), h->max_ch);
     h->timing = timing;
     if (rc) return rc;
-    GPSMI_HIP(hipEventRecord(h->stage_free[s], h->stream));
-    h->stage_used[s] = true;
+    if (!in_line) {
+        GPSMI_HIP(hipEventRecord(h->stage_free[s], h->stream));
+        h->stage_used[s] = true;
+    } else {
+        h->stage_used[s] = false;           // (same stream: the next writer of this block queues behind its readers)
+    }
     if (out)
         GPSMI_HIP(hipMemcpyAsync(out, sl.d_out, h->rows() * sizeof(gpsmi_trk_out),
                                  hipMemcpyDeviceToHost, h->stream));

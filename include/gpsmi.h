@@ -227,9 +227,10 @@ int gpsmi_trk_process_dev(gpsmi_trk* h, const void* d_iq, size_t n,
 
 /* The same for a stream that arrives in host memory, without a host wait per block: the block
  * (page-locked memory from gpsmi_host_alloc for a full-rate, truly asynchronous copy; n and the
- * format as for gpsmi_trk_process) is uploaded into one of two staging blocks on a stream of its
- * own and the kernels are enqueued behind the upload, so the call returns at once and the upload
- * of block k + 1 runs under the kernels of block k.  iq must stay untouched until a later call
+ * format as for gpsmi_trk_process) is uploaded into one of two staging blocks and the kernels are
+ * enqueued behind the upload, so the call returns at once and the host runs ahead of the device;
+ * steps of more than 8 MiB upload on a stream of their own under the kernels of the step before
+ * (GPSMI_STREAM_INLINE_MAX moves that size).  iq must stay untouched until a later call
  * has returned twice or gpsmi_trk_wait has; out (optional, page-locked) is filled when
  * gpsmi_trk_wait returns or the call after next has been enqueued and waited for.  This is
  * streamData -> pushToBuffer -> processData (gpsrecv.py:153-186, :76-104, :445-548) with the ring

@@ -132,10 +132,15 @@ def test_raw_u8_flow_equals_complex64_flow():
     rx_b.close()
 
 
-def test_streamed_blocks_equal_blocking_calls():
-    """gpsmi_trk_process_stream: blocks from pinned host memory, upload on its own stream under
-    the previous block's kernels, no host wait per block.  Raw uint16 and complex64 input; the
-    records of every block must equal those of the blocking gpsmi_trk_process."""
+@pytest.mark.parametrize('inline_max', [None, '0'])
+def test_streamed_blocks_equal_blocking_calls(monkeypatch, inline_max):
+    """gpsmi_trk_process_stream: blocks from pinned host memory, no host wait per block; the
+    upload in front of the block's own kernels on the main stream (the default for steps up to
+    8 MiB) or, GPSMI_STREAM_INLINE_MAX=0, on the upload stream under the previous block's kernels
+    (two staging blocks, events both ways).  Raw uint16 and complex64 input; the records of every
+    block must equal those of the blocking gpsmi_trk_process."""
+    if inline_max is not None:
+        monkeypatch.setenv('GPSMI_STREAM_INLINE_MAX', inline_max)
     from conftest import load_golden, scene_for
     from gpsmi.engine import TrkEngine, PinnedArray, OUT_DTYPE
     g = load_golden('ref_default.npz')
