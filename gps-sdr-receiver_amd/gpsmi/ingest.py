@@ -1,7 +1,10 @@
 """Ingest side of the receiver: the raw-file reader and the overflow-dropping
 ring buffer of reference src/gpsrecv.py:47-104, :153-186, with the sample decode
 (``(I + jQ)/127.5 - (1+1j)``, gpsrecv.py:170-172) done on the GPU so that only
-2 bytes per sample cross PCIe instead of 8."""
+2 bytes per sample cross PCIe instead of 8.  ``StreamedInput`` is the consumer end
+of that ring buffer on the GPU: blocks go from a small ring of page-locked buffers
+into the tracking engine without a host wait per block
+(``gpsmi_trk_process_stream``)."""
 from collections import deque
 
 import numpy as np
@@ -86,3 +89,51 @@ class DeviceIngest:
     def free(self):
         self.d_raw.free()
         self.d_iq.free()
+
+
+class StreamedInput:
+    """streamData -> pushToBuffer -> processData (gpsrecv.py:153-186, :76-104, :445-548) with the
+    consumer on the GPU: ``feed(block)`` copies the block (one per stream of the engine, raw uint16
+    after ``trk.set_input_format(True)``, complex64 otherwise) into the next of `depth` page-locked
+    buffers and enqueues upload + tracking kernels; nothing waits for the device until ``drain()``.
+    With `keep_outputs` every block's records are read back (valid after drain())."""
+
+    def __init__(self, trk, depth=3, keep_outputs=False):
+        if depth < 3:
+            raise ValueError('three buffers at least: one filled, one in flight, one being read')
+        self.trk = trk
+        dt = np.uint16 if getattr(trk, 'raw_u8', False) else np.complex64
+        shape = (trk.streams, trk.cfg.ngps)
+        self.ring = [E.PinnedArray(shape, dt) for _ in range(depth)]
+        self.k = 0
+        self.keep = keep_outputs
+        self.outs = []
+
+    def feed(self, block):
+        # (a buffer is rewritten `depth` >= 3 calls after it was handed to the device: two later calls
+        # have returned since, which is what gpsmi_trk_process_stream asks for)
+        slot = self.ring[self.k % len(self.ring)]
+        slot.array[...] = np.asarray(block).reshape(slot.array.shape)
+        out = None
+        if self.keep:
+            out = E.PinnedArray((self.trk.streams, self.trk.max_ch), E.OUT_DTYPE)
+            self.outs.append(out)
+        self.trk.process_stream(slot.array, out.array if out is not None else None)
+        self.k += 1
+
+    def drain(self):
+        """Wait for everything enqueued; returns the kept records as one array [blocks, streams, ch]."""
+        self.trk.wait()
+        res = None
+        if self.keep and self.outs:
+            res = np.stack([o.array.copy() for o in self.outs])
+            for o in self.outs:
+                o.free()
+            self.outs = []
+        return res
+
+    def free(self):
+        self.trk.wait()
+        for p in self.ring:
+            p.free()
+        self.ring = []

@@ -167,3 +167,37 @@ def test_streamed_blocks_equal_blocking_calls(monkeypatch, inline_max):
             e.close()
         for p_ in pins + outs:
             p_.free()
+
+
+def test_streamed_input_ring_equals_blocking_calls():
+    """gpsmi.ingest.StreamedInput: the GPU end of the reference's ring buffer -- raw blocks pulled
+    from a RingBuffer, fed through three page-locked buffers without a host wait per block -- gives
+    the records of the blocking calls, block for block."""
+    from conftest import load_golden, scene_for
+    from gpsmi.engine import TrkEngine
+    from gpsmi.ingest import RingBuffer, StreamedInput
+    g = load_golden('ref_default.npz')
+    sc = scene_for('default')
+    nch, n = 4, 9
+    raw = [sc.block_raw(5 + i) for i in range(n)]
+    engs = [TrkEngine(max_ch=nch) for _ in range(2)]
+    for e in engs:
+        e.set_input_format(True)
+        for c, (sv, f0, d0) in enumerate(g['trk_init'][:nch]):
+            e.open(c, int(sv), float(f0), int(d0))
+    want = np.stack([engs[0].process(b) for b in raw])
+    rb = RingBuffer()
+    for b in raw:
+        rb.push(b)
+    si = StreamedInput(engs[1], keep_outputs=True)
+    while True:
+        data, skip = rb.pull()
+        if len(data) == 0:
+            break
+        assert skip == 0
+        si.feed(data)
+    got = si.drain()
+    assert got.shape == (n, 1, nch) and got[:, 0].tobytes() == want.tobytes()
+    si.free()
+    for e in engs:
+        e.close()
