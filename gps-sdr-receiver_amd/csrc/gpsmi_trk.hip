@@ -425,6 +425,8 @@ struct gpsmi_trk {
     void* d_stage[2] = {nullptr, nullptr};
     size_t stage_bytes = 0;
     hipEvent_t up_done[2] = {nullptr, nullptr}, stage_free[2] = {nullptr, nullptr};
+    hipEvent_t in_done[2] = {nullptr, nullptr};   // end of a streamed step (its iq read, its out written)
+    bool in_pending[2] = {false, false};
     bool stage_used[2] = {false, false};
     int stage_idx = 0;
     size_t stream_inline_max = 8u << 20;     // bytes up to which a streamed block is copied on the main stream
@@ -727,6 +729,7 @@ static int trk_settle(gpsmi_trk* h) {
     GPSMI_HIP(hipStreamSynchronize(h->stream));
     GPSMI_HIP(hipStreamSynchronize(h->epi_stream));
     h->slot[0].epi_pending = h->slot[1].epi_pending = false;
+    h->in_pending[0] = h->in_pending[1] = false;
     if (h->slot[0].copy_pending || h->slot[1].copy_pending)
         GPSMI_HIP(hipStreamSynchronize(h->copy_stream));
     for (int k = 0; k < 2; ++k) {          // older slot first: last_*_ms end up with the latest run
@@ -922,6 +925,7 @@ int gpsmi_trk_destroy(gpsmi_trk* h) {
         if (h->d_stage[k]) (void)hipFree(h->d_stage[k]);
         if (h->up_done[k]) (void)hipEventDestroy(h->up_done[k]);
         if (h->stage_free[k]) (void)hipEventDestroy(h->stage_free[k]);
+        if (h->in_done[k]) (void)hipEventDestroy(h->in_done[k]);
     }
     if (h->up_stream) (void)hipStreamDestroy(h->up_stream);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
@@ -1094,6 +1098,7 @@ int gpsmi_trk_process_stream(gpsmi_trk* h, const void* iq, size_t n, gpsmi_trk_o
         for (int k = 0; k < 2; ++k) {
             GPSMI_HIP(hipEventCreateWithFlags(&h->up_done[k], hipEventDisableTiming));
             GPSMI_HIP(hipEventCreateWithFlags(&h->stage_free[k], hipEventDisableTiming));
+            GPSMI_HIP(hipEventCreateWithFlags(&h->in_done[k], hipEventDisableTiming));
         }
     }
     if (bytes > h->stage_bytes) {
@@ -1117,6 +1122,13 @@ int gpsmi_trk_process_stream(gpsmi_trk* h, const void* iq, size_t n, gpsmi_trk_o
     }
     const int s = h->stage_idx;
     h->stage_idx ^= 1;
+    // back-pressure: the step of the call before last has finished when this call returns (its iq may
+    // be rewritten, its out is filled) -- the contract of gpsmi.h; the host therefore runs at most two
+    // steps ahead of the device, which keeps one whole step queued behind the one that is running
+    if (h->in_pending[s]) {
+        GPSMI_HIP(hipEventSynchronize(h->in_done[s]));
+        h->in_pending[s] = false;
+    }
     // page-locked memory is read by a kernel (see stage_copy_kernel); anything else -- pageable
     // memory would fault under a kernel -- goes through the runtime's copy
     bool pinned = false;
@@ -1171,6 +1183,8 @@ int gpsmi_trk_process_stream(gpsmi_trk* h, const void* iq, size_t n, gpsmi_trk_o
     if (out)
         GPSMI_HIP(hipMemcpyAsync(out, sl.d_out, h->rows() * sizeof(gpsmi_trk_out),
                                  hipMemcpyDeviceToHost, h->stream));
+    GPSMI_HIP(hipEventRecord(h->in_done[s], h->stream));
+    h->in_pending[s] = true;
     return GPSMI_OK;
 }
 

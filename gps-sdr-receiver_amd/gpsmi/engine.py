@@ -317,10 +317,11 @@ class TrkEngine:
         return out
 
     def process_stream(self, iq, out=None):
-        """One closed-loop block (per stream) from host memory without a host wait: the
-        upload runs on its own stream under the previous block's kernels
-        (gpsmi_trk_process_stream).  iq: a C-contiguous array in the handle's input format,
-        ideally a PinnedArray's; out: optional pinned OUT_DTYPE array, valid after wait()."""
+        """One closed-loop block (per stream) from host memory without waiting for it
+        (gpsmi_trk_process_stream): the call returns once the step of the call before last is
+        complete, i.e. the host runs at most two steps ahead.  iq: a C-contiguous array in the
+        handle's input format, ideally a PinnedArray's, untouched until two later calls (or
+        wait()) have returned; out: optional pinned OUT_DTYPE array, valid from the same moment."""
         n = self.streams * self.cfg.ngps
         if iq.size != n or iq.dtype != (np.uint16 if getattr(self, 'raw_u8', False) else np.complex64):
             raise TypeError('block size or dtype does not match the handle')

@@ -95,45 +95,52 @@ class StreamedInput:
     """streamData -> pushToBuffer -> processData (gpsrecv.py:153-186, :76-104, :445-548) with the
     consumer on the GPU: ``feed(block)`` copies the block (one per stream of the engine, raw uint16
     after ``trk.set_input_format(True)``, complex64 otherwise) into the next of `depth` page-locked
-    buffers and enqueues upload + tracking kernels; nothing waits for the device until ``drain()``.
-    With `keep_outputs` every block's records are read back (valid after drain())."""
+    buffers and enqueues upload + tracking kernels without waiting for them.  The library lets the
+    host run two steps ahead (gpsmi_trk_process_stream returns once the step before last is done),
+    so three buffers are enough and the memory in use is bounded however long the stream is.
+    With `keep_outputs`, ``feed`` returns the records [streams, ch] of the block fed two calls
+    earlier (None for the first two) and ``drain()`` the ones still outstanding."""
 
     def __init__(self, trk, depth=3, keep_outputs=False):
         if depth < 3:
-            raise ValueError('three buffers at least: one filled, one in flight, one being read')
+            raise ValueError('three buffers at least: one being filled, two with the device')
         self.trk = trk
         dt = np.uint16 if getattr(trk, 'raw_u8', False) else np.complex64
         shape = (trk.streams, trk.cfg.ngps)
         self.ring = [E.PinnedArray(shape, dt) for _ in range(depth)]
-        self.k = 0
         self.keep = keep_outputs
-        self.outs = []
+        self.outs = ([E.PinnedArray((trk.streams, trk.max_ch), E.OUT_DTYPE) for _ in range(depth)]
+                     if keep_outputs else [])
+        self.k = 0           # blocks fed
+        self.taken = 0       # records handed back
 
     def feed(self, block):
-        # (a buffer is rewritten `depth` >= 3 calls after it was handed to the device: two later calls
-        # have returned since, which is what gpsmi_trk_process_stream asks for)
-        slot = self.ring[self.k % len(self.ring)]
+        # (buffer k % depth was last handed over `depth` >= 3 calls ago; the calls since have returned,
+        # so that step is complete -- see the contract in include/gpsmi.h)
+        j = self.k % len(self.ring)
+        slot = self.ring[j]
         slot.array[...] = np.asarray(block).reshape(slot.array.shape)
-        out = None
-        if self.keep:
-            out = E.PinnedArray((self.trk.streams, self.trk.max_ch), E.OUT_DTYPE)
-            self.outs.append(out)
-        self.trk.process_stream(slot.array, out.array if out is not None else None)
+        self.trk.process_stream(slot.array, self.outs[j].array if self.keep else None)
         self.k += 1
+        if self.keep and self.k - self.taken > 2:
+            return self._take()
+        return None
+
+    def _take(self):
+        rec = self.outs[self.taken % len(self.outs)].array.copy()
+        self.taken += 1
+        return rec
 
     def drain(self):
-        """Wait for everything enqueued; returns the kept records as one array [blocks, streams, ch]."""
+        """Wait for everything enqueued; returns the records not yet handed back [blocks, streams, ch]
+        (None without keep_outputs or when there are none)."""
         self.trk.wait()
-        res = None
-        if self.keep and self.outs:
-            res = np.stack([o.array.copy() for o in self.outs])
-            for o in self.outs:
-                o.free()
-            self.outs = []
-        return res
+        if not self.keep or self.taken == self.k:
+            return None
+        return np.stack([self._take() for _ in range(self.k - self.taken)])
 
     def free(self):
         self.trk.wait()
-        for p in self.ring:
+        for p in self.ring + self.outs:
             p.free()
-        self.ring = []
+        self.ring, self.outs = [], []

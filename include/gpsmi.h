@@ -228,11 +228,11 @@ int gpsmi_trk_process_dev(gpsmi_trk* h, const void* d_iq, size_t n,
 /* The same for a stream that arrives in host memory, without a host wait per block: the block
  * (page-locked memory from gpsmi_host_alloc for a full-rate, truly asynchronous copy; n and the
  * format as for gpsmi_trk_process) is uploaded into one of two staging blocks and the kernels are
- * enqueued behind the upload, so the call returns at once and the host runs ahead of the device;
- * steps of more than 8 MiB upload on a stream of their own under the kernels of the step before
- * (GPSMI_STREAM_INLINE_MAX moves that size).  iq must stay untouched until a later call
- * has returned twice or gpsmi_trk_wait has; out (optional, page-locked) is filled when
- * gpsmi_trk_wait returns or the call after next has been enqueued and waited for.  This is
+ * enqueued behind the upload, so the call returns without waiting for its own step and the host
+ * runs up to two steps ahead of the device; steps of more than 8 MiB upload on a stream of their
+ * own under the kernels of the step before (GPSMI_STREAM_INLINE_MAX moves that size).  A call
+ * returns once the step of the call BEFORE LAST has finished: from then on that step's iq may be
+ * rewritten and its out (optional, page-locked) is filled; gpsmi_trk_wait finishes all of them.  This is
  * streamData -> pushToBuffer -> processData (gpsrecv.py:153-186, :76-104, :445-548) with the ring
  * buffer's consumer on the GPU.                                                        */
 int gpsmi_trk_process_stream(gpsmi_trk* h, const void* iq, size_t n, gpsmi_trk_out* out);

@@ -138,7 +138,8 @@ def test_streamed_blocks_equal_blocking_calls(monkeypatch, inline_max):
     upload in front of the block's own kernels on the main stream (the default for steps up to
     8 MiB) or, GPSMI_STREAM_INLINE_MAX=0, on the upload stream under the previous block's kernels
     (two staging blocks, events both ways).  Raw uint16 and complex64 input; the records of every
-    block must equal those of the blocking gpsmi_trk_process."""
+    block must equal those of the blocking gpsmi_trk_process, and a call returns only once the step
+    before last is complete (the host never runs more than two steps ahead: three buffers suffice)."""
     if inline_max is not None:
         monkeypatch.setenv('GPSMI_STREAM_INLINE_MAX', inline_max)
     from conftest import load_golden, scene_for
@@ -160,6 +161,8 @@ def test_streamed_blocks_equal_blocking_calls(monkeypatch, inline_max):
         for i, b in enumerate(blocks):
             pins[i % 3].array[:] = b                      # (three buffers: one is never rewritten
             engs[1].process_stream(pins[i % 3].array, outs[i].array)   # while it may still be read)
+            if i >= 2:      # the contract: this call returned, so the step before last is complete
+                assert outs[i - 2].array.tobytes() == want[i - 2], (raw_u8, i, 'back-pressure')
         engs[1].wait()
         for i in range(n):
             assert outs[i].array.tobytes() == want[i], (raw_u8, i)
@@ -172,7 +175,8 @@ def test_streamed_blocks_equal_blocking_calls(monkeypatch, inline_max):
 def test_streamed_input_ring_equals_blocking_calls():
     """gpsmi.ingest.StreamedInput: the GPU end of the reference's ring buffer -- raw blocks pulled
     from a RingBuffer, fed through three page-locked buffers without a host wait per block -- gives
-    the records of the blocking calls, block for block."""
+    the records of the blocking calls, block for block; feed() hands back the records of the block
+    before last, drain() the rest."""
     from conftest import load_golden, scene_for
     from gpsmi.engine import TrkEngine
     from gpsmi.ingest import RingBuffer, StreamedInput
@@ -190,13 +194,18 @@ def test_streamed_input_ring_equals_blocking_calls():
     for b in raw:
         rb.push(b)
     si = StreamedInput(engs[1], keep_outputs=True)
+    early = []
     while True:
         data, skip = rb.pull()
         if len(data) == 0:
             break
         assert skip == 0
-        si.feed(data)
-    got = si.drain()
+        r = si.feed(data)
+        if r is not None:                      # (the records of the block fed two calls earlier)
+            early.append(r)
+    assert len(early) == n - 2
+    got = np.concatenate([np.stack(early), si.drain()])
+    assert si.drain() is None
     assert got.shape == (n, 1, nch) and got[:, 0].tobytes() == want.tobytes()
     si.free()
     for e in engs:
