@@ -947,9 +947,9 @@ int gpsmi_trk_set_replica(gpsmi_trk* h, int prn, const float* replica, const flo
                             hipMemcpyHostToDevice));
         GPSMI_HIP(hipMemcpy(h->d_code2 + (size_t)prn * 2 * kFftN + kFftN, replica,
                             kFftN * sizeof(float), hipMemcpyHostToDevice));
-        std::vector<float> eo(2 * kFftN);          // plane e, entry s = replica[2 (s mod 1024) + e]
-        for (int e = 0; e < 2; ++e)
-            for (int i = 0; i < kFftN; ++i) eo[e * kFftN + i] = replica[2 * (i % (kFftN / 2)) + e];
+        std::vector<float> eo(2 * kFftN);          // plane e of four, entry h = replica[(4 h + e) mod 2048], 1024 entries
+        for (int e = 0; e < 4; ++e)
+            for (int i = 0; i < kFftN / 2; ++i) eo[e * (kFftN / 2) + i] = replica[(4 * i + e) % kFftN];
         GPSMI_HIP(hipMemcpy(h->d_code_eo + (size_t)prn * 2 * kFftN, eo.data(), eo.size() * sizeof(float),
                             hipMemcpyHostToDevice));
     }

@@ -45,6 +45,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+
 #include <type_traits>
 
 namespace gpsmi {
@@ -57,7 +58,7 @@ constexpr int kSpTileFloats = 32 * kSpRowDw;
 constexpr int kSpWin = 32;                     // positions per replica window
 constexpr int kSpCodePitch = kSpWin / 2 + 4;   // floats per (channel, parity) row of a window
 constexpr int kSpCodeFloats = kSpCh * 2 * kSpCodePitch;
-constexpr int kSpWaveFloats = kSpTileFloats + kSpCodeFloats;     // 4640 floats = 18,560 B per wave
+constexpr int kSpWaveFloats = kSpTileFloats;                     // 4160 floats = 16,640 B per wave
 constexpr int kSpInf = 1 << 20;
 
 
@@ -98,37 +99,6 @@ __device__ __forceinline__ float2 sp_window(float hx, float hy, float lx, float 
     return make_float2(re, im);
 }
 
-// B of four pairs for both N tiles and two steps of the recurrence, in program order:
-// every B value is written at least four instructions before the block ends, so the MFMAs
-// behind it need no wait state.  nk = (-kappa of tile 0, -kappa of tile 1).
-__device__ __forceinline__ void sp_b4(sp4 c0, sp4 c1, sp2 nk, sp2& u0, sp2& dl0, sp2& u1, sp2& dl1,
-                                      sp2& b00, sp2& b01, sp2& b10, sp2& b11) {
-    const sp2 c0a = {c0.x, c0.y}, c0b = {c0.z, c0.w}, c1a = {c1.x, c1.y}, c1b = {c1.z, c1.w};
-    asm("v_pk_mul_f32 %0, %8, %4\n\t"
-        "v_pk_mul_f32 %2, %10, %6\n\t"
-        "v_pk_fma_f32 %5, %12, %4, %5 op_sel_hi:[0,1,1]\n\t"
-        "v_pk_fma_f32 %7, %12, %6, %7 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
-        "v_pk_add_f32 %4, %4, %5\n\t"
-        "v_pk_add_f32 %6, %6, %7\n\t"
-        "v_pk_mul_f32 %1, %9, %4\n\t"
-        "v_pk_mul_f32 %3, %11, %6\n\t"
-        "v_pk_fma_f32 %5, %12, %4, %5 op_sel_hi:[0,1,1]\n\t"
-        "v_pk_fma_f32 %7, %12, %6, %7 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
-        "v_pk_add_f32 %4, %4, %5\n\t"
-        "v_pk_add_f32 %6, %6, %7"
-        : "=&v"(b00), "=&v"(b01), "=&v"(b10), "=&v"(b11), "+v"(u0), "+v"(dl0), "+v"(u1), "+v"(dl1)
-        : "v"(c0a), "v"(c0b), "v"(c1a), "v"(c1b), "v"(nk));
-}
-// the recurrence alone (the positions before a range that starts inside a quarter)
-__device__ __forceinline__ void sp_rec(sp2 nk, sp2& u0, sp2& dl0, sp2& u1, sp2& dl1) {
-    asm("v_pk_fma_f32 %1, %4, %0, %1 op_sel_hi:[0,1,1]\n\t"
-        "v_pk_fma_f32 %3, %4, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
-        "v_pk_add_f32 %0, %0, %1\n\t"
-        "v_pk_add_f32 %2, %2, %3"
-        : "+v"(u0), "+v"(dl0), "+v"(u1), "+v"(dl1)
-        : "v"(nk));
-}
-
 __device__ __forceinline__ int sp_wave_min(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -149,20 +119,6 @@ __device__ __forceinline__ SpDesc sp_desc(const JobMid* __restrict__ midrow, int
     d.delay_used = m.delay_used; d.active = have && m.active; d.prn = m.prn; d.om = m.om; d.ph = m.ph;
     return d;
 }
-// the descriptors of a wave's lane roles: its two channels (one per N tile) and, for the lanes
-// that stage the replica (l < 48), the channel l / 4
-__device__ __forceinline__ void sp_wave_descs(const JobMid* __restrict__ midrow, int nch_g, int lane,
-                                              SpDesc (&md)[2], SpDesc& smd) {
-    const int j = lane & 15;
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        const int c = 8 * n + (j >> 1);
-        md[n] = sp_desc(midrow, c, c < kSpCh && c < nch_g);
-    }
-    const int sc = lane >> 2;
-    smd = sp_desc(midrow, sc, lane < 4 * kSpCh && sc < nch_g);
-}
-
 // ---- tile staging: 16 x b128 per lane; instruction i covers rows 2 i, 2 i + 1 (lane / 32) and
 // 512 bytes of each.  Global address = scalar base + one lane offset (buffer loads; a tile
 // position past the block reads nothing and returns zeros).  The rows are read once:
@@ -236,117 +192,191 @@ __device__ __forceinline__ void sp_store_tile(float* tl, int lane, const sp4 (&s
     }
 }
 
+// The staged tile into LDS and the request for the next one, piece by piece: a register quad is
+// asked for again as soon as it has been written to LDS, so a wave's requests never drain to zero
+// while it waits for the last rows of a tile and stores them (loads return in order: the wait in
+// front of piece i lets the 15 requests behind it stay in flight).
+template <int AUX, int FMT>
+__device__ __forceinline__ void sp_swap_tile(float* tl, int lane, sp4 (&st)[16], const void* blk, int pos) {
+    constexpr int CS = kFftN, NC = 32;
+    if (FMT == 0) {
+        const __amdgpu_buffer_rsrc_t blk_rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<void*>(blk), 0, CS * NC * (int)sizeof(float2), kMfRsrcFlags);
+        const int ld_off = ((lane >> 5) * CS + 2 * (lane & 31)) * (int)sizeof(float2);
+        const int tb = pos * (int)sizeof(float2);
+        const int swz = ((lane & 31) >> 3) & 1;              // (see sp_store_tile)
+        float* st_dst = tl + (lane >> 5) * kSpRowDw + 4 * (lane & 31);
+        float* d0 = st_dst + 2 * swz;
+        float* d1 = st_dst + 2 * (1 - swz);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            *reinterpret_cast<sp2*>(d0 + i * 2 * kSpRowDw) = sp2{st[i].x, st[i].y};
+            *reinterpret_cast<sp2*>(d1 + i * 2 * kSpRowDw) = sp2{st[i].z, st[i].w};
+            __builtin_amdgcn_sched_barrier(0);
+            st[i] = __builtin_bit_cast(sp4, __builtin_amdgcn_raw_buffer_load_b128(
+                blk_rs, ld_off, tb + i * (2 * CS * (int)sizeof(float2)), AUX));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        sp_store_tile<FMT>(tl, lane, st);
+        sp_load_tile<AUX, FMT>(blk, pos, lane, st);
+    }
+}
+
+// ======================================================================================
+// Three real products per complex one (round 3).  y = sum x B with x = a + j b, B = c + j d:
+//     P1 = (a + b) c,   P2 = a (d - c),   P3 = b (c + d):   re = P1 - P3,  im = P1 + P2,
+// so a K-step of FOUR positions is three real matrix products with N = channel (12 of 16
+// columns) instead of four products per PAIR with N = (channel, re/im): 96 MFMAs per tile of
+// 32 rows x 64 positions where the four-product form needs 128.  The three B components
+// (z.re, z.im - z.re, z.re + z.im of the carrier phasor z) are linear in (cos, sin): each
+// follows the same coupled recurrence, one lane = one channel at positions m, m + 4 in a
+// packed pair advanced eight positions per step (kappa = 4 sin^2(4 phi)).  a + b costs one
+// v_add_f32 per A operand.  The replica comes straight from a table split by index mod 4
+// (a lane's positions are 4 apart): 16 consecutive entries per lane and tile, no LDS stage.
+//   A[r][k]  = (a + b | a | b) of x[r][4 s + k],        lane = (row r = lane % 16, k = lane / 16)
+//   B[k][c]  = replica_c[(m - d_c) mod 2048] * (u1 | u2 | u3)_c(m), m = 4 s + k, lane = (c, k)
+//   D[r][c]  = three accumulators k1, k2, k3 per M tile, lane = (c, row group)
+// ======================================================================================
+// the descriptor of a wave's lane role: channel lane % 16
+__device__ __forceinline__ void sp_wave_desc(const JobMid* __restrict__ midrow, int nch_g, int lane, SpDesc& cmd) {
+    const int c = lane & 15;
+    cmd = sp_desc(midrow, c, c < kSpCh && c < nch_g);
+}
+
+// B of two K-steps (positions m and m + 4 of the lane) for the three products, then one step of
+// the recurrences; every B value is written six instructions before the block ends
+__device__ __forceinline__ void sp_b3(sp2 cd, sp2 nk, sp2& u1, sp2& d1, sp2& u2, sp2& d2, sp2& u3, sp2& d3,
+                                      sp2& b1, sp2& b2, sp2& b3) {
+    asm("v_pk_mul_f32 %0, %9, %3\n\t"
+        "v_pk_mul_f32 %1, %9, %5\n\t"
+        "v_pk_mul_f32 %2, %9, %7\n\t"
+        "v_pk_fma_f32 %4, %10, %3, %4\n\t"
+        "v_pk_fma_f32 %6, %10, %5, %6\n\t"
+        "v_pk_fma_f32 %8, %10, %7, %8\n\t"
+        "v_pk_add_f32 %3, %3, %4\n\t"
+        "v_pk_add_f32 %5, %5, %6\n\t"
+        "v_pk_add_f32 %7, %7, %8"
+        : "=&v"(b1), "=&v"(b2), "=&v"(b3), "+v"(u1), "+v"(d1), "+v"(u2), "+v"(d2), "+v"(u3), "+v"(d3)
+        : "v"(cd), "v"(nk));
+}
+// the recurrences alone (the positions before a range that starts inside a quarter)
+__device__ __forceinline__ void sp_rec3(sp2 nk, sp2& u1, sp2& d1, sp2& u2, sp2& d2, sp2& u3, sp2& d3) {
+    asm("v_pk_fma_f32 %1, %6, %0, %1\n\t"
+        "v_pk_fma_f32 %3, %6, %2, %3\n\t"
+        "v_pk_fma_f32 %5, %6, %4, %5\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_add_f32 %2, %2, %3\n\t"
+        "v_pk_add_f32 %4, %4, %5"
+        : "+v"(u1), "+v"(d1), "+v"(u2), "+v"(d2), "+v"(u3), "+v"(d3)
+        : "v"(nk));
+}
+
 // One wave: NSPANS consecutive spans starting at position `pos0` (a multiple of 64) of a
 // block.  The caller has requested the first tile into `st` (sp_load_tile) and fetched the
-// descriptors; on return `st` holds the request for the tile at `next_pos` of `next_blk` (the
-// first tile of the wave's next range, or a position past the block: nothing).  Returns the
-// sums of the range for [M tile][N tile] in (tot, lo_fin): lo_fin = what was summed below the
-// delay when the boundary lies inside the range, tot = the rest.
+// descriptor; on return `st` holds the request for the tile at `next_pos` of `next_blk` (the
+// first tile of the wave's next range, or a position past the block: nothing).  Returns in
+// `tot` the sums of the range for [M tile][re, im] of the lane's channel that lie above the
+// delay (everything, if the boundary is not inside the range); what was summed below a
+// boundary inside the range is handed to `close(mt, re, im)` at the moment the boundary passes,
+// for the lanes of that channel only (the caller keeps it in registers or in LDS: 16 registers
+// held through the tile loop for an event that happens once per channel and block were the
+// difference between spilling and not).  `after_first_swap()` runs once, behind the first
+// tile's store / request sequence: the place for loads that must not wait behind rows.
 // (DIAG: tools/probe/span_prof.hip only -- 1 no MFMAs, 2 no row loads after the first tile, 8 default
 // cache policy; the library instantiates DIAG = 0 alone, where every test of it folds away)
-template <int NSPANS, int FMT = 0, int DIAG = 0>
+template <int NSPANS, int FMT = 0, int DIAG = 0, class Close, class Hook>
 __device__ __forceinline__ void span_wave(const void* __restrict__ blk, const void* next_blk,
-                                          int next_pos, float* tl, float* cd, const SpDesc (&mdd)[2],
-                                          const SpDesc& smd, const float* __restrict__ code_eo,
-                                          int pos0, int lane, sp4 (&st)[16], sp4 (&tot)[2][2],
-                                          sp4 (&lo_fin)[2][2], bool (&all_lo)[2], int (&pb)[2]) {
+                                          int next_pos, float* tl, const SpDesc& cmd,
+                                          const float* __restrict__ code_q4, int pos0, int lane,
+                                          sp4 (&st)[16], sp4 (&tot)[2][2], bool& all_lo, int& pb,
+                                          Close&& close, Hook&& after_first_swap) {
     constexpr int CS = kFftN;
-    const int j = lane & 15, k = lane >> 4, pi = k >> 1, kap = k & 1, part = j & 1;
+    const int k = lane >> 4;
     const int q0 = pos0 & ~(kSpQuarter - 1);                      // start of the quarter
     constexpr int kTiles = NSPANS;
-    auto store_tile = [&]() { sp_store_tile<FMT>(tl, lane, st); };
 
-    // ---- lane roles: two channels (one per N tile); the recurrence of both, seeded with the
-    // exact phasor of the lane's first two positions of the QUARTER
+    // ---- lane role: one channel; the three recurrences, seeded with the exact phasor of the
+    // lane's first two positions (m, m + 4) of the QUARTER
     const double inv_2pi = 0.15915494309189533576888376337251;
     const float inv_fs = 1.0f / (1000.0f * (float)CS);
-    const float sx = ((kap == 0) == (part == 0)) ? 1.f : 0.f;          // (0,re) and (1,im): +z.x
-    const float sy = (sx != 0.f) ? 0.f : (part == 0 ? -1.f : 1.f);     // (1,re): -z.y, (0,im): +z.y
-    // pb: boundary relative to the quarter start, kSpInf if outside (0, 512)
-    const float* crow[2];             // LDS: the lane's replica rows of the current window
-    sp2 u2[2], dl2[2], nk;
-    float nkv[2];
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        const int c = 8 * n + (j >> 1);
-        const SpDesc& md = mdd[n];
-        const bool active = md.active;
-        const float f_eff = active ? (float)((double)md.om * inv_2pi) : 0.f;
-        const float ph_rev = active ? md.ph * (float)inv_2pi : 0.f;
-        const float2 w2 = sp_phasor_rev(2.0f * (f_eff * inv_fs));      // exp(-j 2 phi)
-        const float sh = -w2.y, chh = w2.x;
-        nkv[n] = -4.0f * sh * sh;                                      // -4 sin^2(2 phi): step of four positions
-        const float2 omw4 = make_float2(2.0f * sh * sh, -2.0f * sh * chh);   // 1 - exp(+j 4 phi)
-        const float2 z0 = sp_phasor_rev(fmaf(f_eff, (float)(q0 + pi + 1) * inv_fs, ph_rev));
-        const float2 z1 = sp_cmul(z0, w2);
-        const float2 dz0 = sp_cmul(z0, omw4), dz1 = sp_cmul(z1, omw4);   // z(m) - z(m - 4)
-        u2[n] = sp2{active ? fmaf(sx, z0.x, sy * z0.y) : 0.f, active ? fmaf(sx, z1.x, sy * z1.y) : 0.f};
-        dl2[n] = sp2{active ? fmaf(sx, dz0.x, sy * dz0.y) : 0.f,
-                     active ? fmaf(sx, dz1.x, sy * dz1.y) : 0.f};
-        const int d = active ? md.delay_used : 0;
-        const int rel = d - q0;                                        // boundary relative to the quarter
-        all_lo[n] = active && rel >= kSpQuarter;
-        pb[n] = (active && rel > 0 && rel < kSpQuarter) ? rel : kSpInf;
-        crow[n] = cd + ((c < kSpCh ? c : 0) * 2 + pi) * kSpCodePitch;
+    const bool active = cmd.active;
+    sp2 u1, u2, u3, d1, d2, d3, nk;
+    {
+        const float f_eff = active ? (float)((double)cmd.om * inv_2pi) : 0.f;
+        const float ph_rev = active ? cmd.ph * (float)inv_2pi : 0.f;
+        const float2 w4 = sp_phasor_rev(4.0f * (f_eff * inv_fs));      // exp(-j 4 phi)
+        const float sh = -w4.y, chh = w4.x;
+        const float nkv = -4.0f * sh * sh;                             // -4 sin^2(4 phi): step of eight positions
+        const float2 omw8 = make_float2(2.0f * sh * sh, -2.0f * sh * chh);   // 1 - exp(+j 8 phi)
+        const float2 z0 = sp_phasor_rev(fmaf(f_eff, (float)(q0 + k + 1) * inv_fs, ph_rev));
+        const float2 z1 = sp_cmul(z0, w4);
+        const float2 dz0 = sp_cmul(z0, omw8), dz1 = sp_cmul(z1, omw8);   // z(m) - z(m - 8)
+        const float on = active ? 1.f : 0.f;
+        u1 = sp2{on * z0.x, on * z1.x};
+        u2 = sp2{on * (z0.y - z0.x), on * (z1.y - z1.x)};
+        u3 = sp2{on * (z0.x + z0.y), on * (z1.x + z1.y)};
+        d1 = sp2{on * dz0.x, on * dz1.x};
+        d2 = sp2{on * (dz0.y - dz0.x), on * (dz1.y - dz1.x)};
+        d3 = sp2{on * (dz0.x + dz0.y), on * (dz1.x + dz1.y)};
+        nk = sp2{nkv, nkv};
     }
-    nk = sp2{nkv[0], nkv[1]};                                          // -kappa of both tiles in one pair
+    const int d_c = active ? cmd.delay_used : 0;
+    {
+        const int rel = d_c - q0;                                      // boundary relative to the quarter
+        all_lo = active && rel >= kSpQuarter;
+        pb = (active && rel > 0 && rel < kSpQuarter) ? rel : kSpInf;   // kSpInf if outside (0, 512)
+    }
     const int rel0 = pos0 - q0;                                        // range start within the quarter
     // a range that starts inside the quarter: the recurrence steps of the positions before it
 #pragma unroll 1
-    for (int s = 0; s < rel0 / 4; ++s) sp_rec(nk, u2[0], dl2[0], u2[1], dl2[1]);
+    for (int s = 0; s < rel0 / 8; ++s) sp_rec3(nk, u1, d1, u2, d2, u3, d3);
 
-    // ---- replica staging: lane l < 48 fetches 8 consecutive entries of one (channel, parity)
-    // row of a 32-position window: channel l / 4, parity (l / 2) & 1, half l & 1.  Tile
-    // position m = 2 q + pi, rolled index r = (m - d) mod 2048 has parity e = (pi - d) & 1 and
-    // half index (r - e) / 2, which advances by one per pair: a contiguous run of the table
-    // plane e (doubled, so the run never wraps).  A closed channel reads PRN slot 0 (zeros).
-    const int sc = lane >> 2, spl = (lane >> 1) & 1, shf = lane & 1;
-    const bool s_act = smd.active;
+    // ---- replica: position m = 4 s + k of the tile, rolled index r = (m - d) mod 2048 = 4 h + e
+    // with e = (pos0 + k - d) & 3 fixed for the lane and h advancing by one per K-step: a
+    // contiguous run of plane e of the table (each plane stored twice over, so the run never
+    // wraps).  A closed channel reads PRN slot 0 (zeros).  Every request for entries is issued
+    // at the top of a tile, IN FRONT of the row requests: loads return in order, so a wait for
+    // entries (or for the registers they land in) never waits for rows.  The second half of the
+    // tile goes straight to its place, the first half of the NEXT tile to a side buffer.
     const __amdgpu_buffer_rsrc_t code_rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(code_eo), 0, (GPSMI_MAX_PRN + 1) * 2 * CS * (int)sizeof(float), kMfRsrcFlags);
-    int sc_off;
+        const_cast<float*>(code_q4), 0, (GPSMI_MAX_PRN + 1) * 2 * CS * (int)sizeof(float), kMfRsrcFlags);
+    int cd_off;
     {
-        const int d = s_act ? smd.delay_used : 0;
-        const int e = (spl - d) & 1;
-        const int hidx = ((pos0 + spl - d - e) & (CS - 1)) >> 1;          // 0 .. 1023
-        sc_off = ((s_act ? smd.prn : 0) * (2 * CS) + e * CS + hidx + 8 * shf) * (int)sizeof(float);
+        const int r0 = (pos0 + k - d_c) & (CS - 1);
+        cd_off = ((active ? cmd.prn : 0) * (2 * CS) + (r0 & 3) * (CS / 2) + (r0 >> 2)) * (int)sizeof(float);
     }
-    float* sdst = cd + ((lane < 4 * kSpCh ? sc : 0) * 2 + spl) * kSpCodePitch + 8 * shf;
-    sp4 cst[2];
-    auto load_code = [&](int win) {                    // window index from pos0, 16 entries each
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            cst[i] = __builtin_bit_cast(sp4, __builtin_amdgcn_raw_buffer_load_b128(
-                code_rs, sc_off, (win * (kSpWin / 2) + 4 * i) * (int)sizeof(float), 0));
+    sp4 cd[4], cdn[2];                                   // K-steps 4 i .. 4 i + 3 of the tile; next tile's first half
+    cdn[0] = sp4{0.f, 0.f, 0.f, 0.f}; cdn[1] = cdn[0];
+    auto load_half = [&](int half, sp4& r0, sp4& r1) {   // half-tile index from pos0, 8 entries
+        r0 = __builtin_bit_cast(sp4, __builtin_amdgcn_raw_buffer_load_b128(
+            code_rs, cd_off, (half * 8) * (int)sizeof(float), 0));
+        r1 = __builtin_bit_cast(sp4, __builtin_amdgcn_raw_buffer_load_b128(
+            code_rs, cd_off, (half * 8 + 4) * (int)sizeof(float), 0));
     };
-    auto store_code = [&]() {
-        if (lane < 4 * kSpCh) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) *reinterpret_cast<sp4*>(sdst + 4 * i) = cst[i];
-        }
-    };
-    load_code(0);
+    load_half(0, cd[0], cd[1]);
 
     const sp4 zero4 = sp4{0.f, 0.f, 0.f, 0.f};
-    sp4 acc[2][2];
+    sp4 k1[2], k2[2], k3[2];                             // the three products per M tile
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int n = 0; n < 2; ++n) { acc[mt][n] = zero4; tot[mt][n] = zero4; lo_fin[mt][n] = zero4; }
-    // the four lanes of a channel close its lo sum where the boundary passes
-    auto close_lo = [&](int n) {
+    for (int mt = 0; mt < 2; ++mt) {
+        k1[mt] = zero4; k2[mt] = zero4; k3[mt] = zero4;
+        tot[mt][0] = zero4; tot[mt][1] = zero4;
+    }
+    // the lanes of a channel close its lo sum where the boundary passes
+    auto close_lo = [&]() {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            lo_fin[mt][n] = tot[mt][n] + acc[mt][n];
-            tot[mt][n] = zero4;
-            acc[mt][n] = zero4;
+            close(mt, tot[mt][0] + (k1[mt] - k3[mt]), tot[mt][1] + (k1[mt] + k2[mt]));
+            tot[mt][0] = zero4; tot[mt][1] = zero4;
+            k1[mt] = zero4; k2[mt] = zero4; k3[mt] = zero4;
         }
     };
-    // the boundaries of the group's channels as scalars (channel c sits in lane 2 (c % 8) of N
-    // tile c / 8): the next one is a dozen scalar compares, no cross-lane reduction in the loop
+    // the boundaries of the group's channels as scalars (channel c sits in lane c): the next one
+    // is a dozen scalar compares, no cross-lane reduction in the loop
     int pbs[kSpCh];
 #pragma unroll
-    for (int c = 0; c < kSpCh; ++c) pbs[c] = __builtin_amdgcn_readlane(pb[c >> 3], 2 * (c & 7));
+    for (int c = 0; c < kSpCh; ++c) pbs[c] = __builtin_amdgcn_readlane(pb, c);
     auto next_boundary = [&](int after) {                            // first boundary position > after
         int v = kSpInf;
 #pragma unroll
@@ -355,142 +385,160 @@ __device__ __forceinline__ void span_wave(const void* __restrict__ blk, const vo
         return v;
     };
     int nb = next_boundary(rel0);        // (a boundary AT the range start needs no action: all hi)
-    const float* ap0 = tl + (lane & 15) * kSpRowDw + k;              // lane = (row, k), rows 0 .. 15
-    const float* ap1 = ap0 + 16 * kSpRowDw;                          // rows 16 .. 31
-    // pairs 8 .. 15 and 24 .. 31 of a complex64 tile sit with their two positions swapped in LDS
-    // (sp_store_tile): the lane of parity pi reads the other half there, k ^ 2
-    const int swz_ofs = FMT == 0 ? (2 - 4 * pi) : 0;                 // (k ^ 2) - k
+    // lane = (row, k) reads the sample at position 4 s + k of its row: 8 bytes.  Pairs 8 .. 15 and
+    // 24 .. 31 of a complex64 tile sit with their two positions swapped in LDS (sp_store_tile):
+    // K-steps 4 .. 7 and 12 .. 15 read the other half of their 16-byte piece
+    const float* ap = tl + (lane & 15) * kSpRowDw + 2 * k;
+    const int swz_ofs = FMT == 0 ? ((k & 1) ? -2 : 2) : 0;
+
+    // operands of one K-step (four positions): the lane's sample of both row halves and re + im
+    struct Ops { sp2 x[2]; float xs[2]; };
+    auto read_ops = [&](int s) {                                     // s: K-step index in the tile
+        Ops o;
+        const float* p = ap + (((s >> 2) & 1) ? swz_ofs : 0) + 8 * s;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) o.x[mt] = *reinterpret_cast<const sp2*>(p + mt * 16 * kSpRowDw);
+        return o;
+    };
+    auto sums = [&](Ops& o) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) o.xs[mt] = o.x[mt].x + o.x[mt].y;
+    };
+    auto mfma = [&](float a, float b, sp4 c) -> sp4 {
+        if (DIAG & 1) { c[0] = fmaf(a, b, c[0]); return c; }
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    };
+    // one K-step: six MFMAs (first: C = 0, an inline constant, no zeroing of the accumulators)
+    auto kstep = [&](const Ops& o, float b1, float b2, float b3, auto first) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            k1[mt] = mfma(o.xs[mt], b1, decltype(first)::value ? zero4 : k1[mt]);
+            k2[mt] = mfma(o.x[mt].x, b2, decltype(first)::value ? zero4 : k2[mt]);
+            k3[mt] = mfma(o.x[mt].y, b3, decltype(first)::value ? zero4 : k3[mt]);
+        }
+    };
+
+    // Tile `t` moves from its registers to LDS: first the entries that tile still needs and the first
+    // ones of the tile after it, then the tile itself piece by piece (the reads of the previous
+    // one are behind us: LDS serves a wave in order) while tile t + 1 is requested (unconditional:
+    // behind the last tile of the range it is the first one of the wave's next range, or a
+    // position past the block, which costs no memory traffic)
+    auto enter_tile = [&](int t) {
+        load_half(2 * t + 1, cd[2], cd[3]);
+        if (t + 1 < kTiles) load_half(2 * t + 2, cdn[0], cdn[1]);    // (the next RANGE fetches its own)
+        if (!(DIAG & 2)) {
+            const bool more = t + 1 < kTiles;              // else: the first tile of the wave's next range
+            sp_swap_tile<(DIAG & 8) ? 0 : 2, FMT>(tl, lane, st, more ? blk : next_blk,
+                                                  more ? pos0 + (t + 1) * kSpTile : next_pos);
+        } else {
+            sp_store_tile<FMT>(tl, lane, st);
+        }
+    };
+    enter_tile(0);
+    after_first_swap();                // (outside the loop: what it holds in registers is dead from here on)
 
 #pragma unroll 1
     for (int tix = 0; tix < kTiles; ++tix) {
-        // the tile that waited in registers goes to LDS (the reads of the previous one are
-        // behind us: LDS serves a wave in order), then the tile after it is requested
-        // (unconditional: behind the last tile of the range it is the first one of the wave's
-        // next range, or a position past the block, which costs no memory traffic)
-        store_code();
-        store_tile();
-        load_code(2 * tix + 1);
-        if (!(DIAG & 2)) {
-            const bool more = tix + 1 < kTiles;            // else: the first tile of the wave's next range
-            sp_load_tile<(DIAG & 8) ? 0 : 2, FMT>(more ? blk : next_blk,
-                                                  more ? pos0 + (tix + 1) * kSpTile : next_pos, lane, st);
-        }
         __builtin_amdgcn_sched_barrier(0);
         const int tpos = rel0 + tix * kSpTile;                       // tile start within the quarter
 
-        // operands of four pairs (eight positions): the lane's component of the samples of
-        // both row halves and the replica entries of its two channels
-        struct Ops { sp4 a0, a1, c0, c1; };
-        auto read_ops = [&](int q4) {                                // q4: pair index in the tile, multiple of 4
-            Ops o;
-            const int sw = ((q4 >> 3) & 1) ? swz_ofs : 0;            // (four pairs never straddle a multiple of 8)
-            const float* a0p = ap0 + sw;
-            const float* a1p = ap1 + sw;
-            o.a0 = sp4{a0p[4 * q4], a0p[4 * q4 + 4], a0p[4 * q4 + 8], a0p[4 * q4 + 12]};
-            o.a1 = sp4{a1p[4 * q4], a1p[4 * q4 + 4], a1p[4 * q4 + 8], a1p[4 * q4 + 12]};
-            o.c0 = *reinterpret_cast<const sp4*>(crow[0] + (q4 & 15));
-            o.c1 = *reinterpret_cast<const sp4*>(crow[1] + (q4 & 15));
-            return o;
-        };
-        auto mfma4 = [&](float a0, float a1, float b0, float b1) {
-            if (DIAG & 1) {
-                acc[0][0][0] = fmaf(a0, b0, acc[0][0][0]);
-                acc[1][1][0] = fmaf(a1, b1, acc[1][1][0]);
-            } else {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
-            }
-        };
-        // the first pair of a span: C = 0 (an inline constant), no zeroing of the accumulators
-        auto mfma4_first = [&](float a0, float a1, float b0, float b1) {
-            if (DIAG & 1) {
-                acc[0][0] = zero4; acc[0][1] = zero4; acc[1][0] = zero4; acc[1][1] = zero4;
-                acc[0][0][0] = a0 * b0;
-                acc[1][1][0] = a1 * b1;
-            } else {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, zero4, 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, zero4, 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, zero4, 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, zero4, 0, 0, 0);
-            }
-        };
-        auto four = [&](const Ops& o, int q4, auto check, auto first) {
-            sp2 b00, b01, b10, b11;
-            sp_b4(o.c0, o.c1, nk, u2[0], dl2[0], u2[1], dl2[1], b00, b01, b10, b11);
-            const float b0v[4] = {b00.x, b00.y, b01.x, b01.y};
-            const float b1v[4] = {b10.x, b10.y, b11.x, b11.y};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float bv[2] = {b0v[i], b1v[i]};
-                if (decltype(check)::value) {
-                    const int P = tpos + 2 * (q4 + i);               // positions P, P + 1
-                    if (nb <= P + 1) {                               // some channel's boundary is here
-                        bool odd[2];
-#pragma unroll
-                        for (int n = 0; n < 2; ++n) {
-                            odd[n] = pb[n] == P + 1;
-                            if (pb[n] == P) close_lo(n);             // even boundary: close lo before the pair
-                        }
-                        if (__builtin_amdgcn_ballot_w64(odd[0] || odd[1]) != 0) {
-                            // position P alone for the boundary lanes, both positions elsewhere
-                            mfma4(o.a0[i], o.a1[i], odd[0] ? (pi == 0 ? bv[0] : 0.f) : bv[0],
-                                  odd[1] ? (pi == 0 ? bv[1] : 0.f) : bv[1]);
-#pragma unroll
-                            for (int n = 0; n < 2; ++n) {
-                                if (odd[n]) close_lo(n);
-                                bv[n] = odd[n] ? (pi == 1 ? bv[n] : 0.f) : 0.f;   // then position P + 1 of those lanes
-                            }
-                        }
-                        nb = next_boundary(P + 1);
-                    }
+        // a K-step that holds boundaries is issued in pieces, B masked to the positions of the
+        // piece, lo closed between them
+        auto kstep_checked = [&](const Ops& o, int s, float b1, float b2, float b3) {
+            const int P = tpos + 4 * s;                              // positions P .. P + 3
+            int done = 0;                                            // positions of the K-step already summed
+            while (nb <= P + 3) {
+                const int t = nb - P;
+                if (t > done) {
+                    const bool in = k >= done && k < t;
+                    kstep(o, in ? b1 : 0.f, in ? b2 : 0.f, in ? b3 : 0.f, std::false_type{});
+                    done = t;
                 }
-                if (decltype(first)::value && i == 0) mfma4_first(o.a0[i], o.a1[i], bv[0], bv[1]);
-                else mfma4(o.a0[i], o.a1[i], bv[0], bv[1]);
+                if (pb == nb) close_lo();
+                nb = next_boundary(nb);
             }
+            const bool in = k >= done;
+            kstep(o, in ? b1 : 0.f, in ? b2 : 0.f, in ? b3 : 0.f, std::false_type{});
         };
-        // one replica window = 16 pairs = four groups of four pairs
+        auto cd_pair = [&](int s2) {                                 // replica entries of K-steps s2, s2 + 1
+            const sp4 v = cd[(s2 >> 2) & 3];
+            return (s2 & 2) ? sp2{v.z, v.w} : sp2{v.x, v.y};
+        };
+        // half a tile = eight K-steps.  The operands of K-step s + 1 are requested from LDS before
+        // the MFMAs of K-step s are issued; B is formed for two K-steps at a time.
         auto half_tile = [&](int hw, auto first) {
-            if (nb >= tpos + (hw + 1) * kSpWin) {
-                Ops o[2];
-                o[0] = read_ops(16 * hw);
+            const bool fast = nb >= tpos + (hw + 1) * (kSpTile / 2);
+            if (!fast && decltype(first)::value) {     // (the accumulators are read where a boundary closes)
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    if (gq + 1 < 4) o[(gq + 1) & 1] = read_ops(16 * hw + 4 * (gq + 1));
+                for (int mt = 0; mt < 2; ++mt) { k1[mt] = zero4; k2[mt] = zero4; k3[mt] = zero4; }
+            }
+            Ops o[2];
+            o[0] = read_ops(8 * hw);
+            sp2 b1, b2, b3;
+            if (fast) {
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    if (s + 1 < 8) o[(s + 1) & 1] = read_ops(8 * hw + s + 1);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (gq == 0) four(o[0], 16 * hw, std::false_type{}, first);
-                    else four(o[gq & 1], 16 * hw + 4 * gq, std::false_type{}, std::false_type{});
+                    sums(o[s & 1]);
+                    if (!(s & 1)) sp_b3(cd_pair(8 * hw + s), nk, u1, d1, u2, d2, u3, d3, b1, b2, b3);
+                    const float c1 = (s & 1) ? b1.y : b1.x, c2 = (s & 1) ? b2.y : b2.x, c3 = (s & 1) ? b3.y : b3.x;
+                    if (s == 0) kstep(o[0], c1, c2, c3, first);
+                    else kstep(o[s & 1], c1, c2, c3, std::false_type{});
                 }
             } else {
-                Ops cur = read_ops(16 * hw);
-                if (decltype(first)::value) {           // (the accumulators are read where a boundary closes)
-                    acc[0][0] = zero4; acc[0][1] = zero4; acc[1][0] = zero4; acc[1][1] = zero4;
-                }
+                // (rolled: one copy of the checked path per half tile; the operands of the next two
+                // K-steps are on their way while these two are summed)
+                o[1] = read_ops(8 * hw + 1);
 #pragma unroll 1
-                for (int q4 = 0; q4 < 16; q4 += 4) {
-                    const Ops nxt = read_ops(16 * hw + (q4 + 4 < 16 ? q4 + 4 : q4));   // last: harmless re-read
+                for (int s = 0; s < 8; s += 2) {
+                    const int sn = s + 2 < 8 ? s + 2 : s;                 // (last: a harmless re-read)
+                    const Ops n0 = read_ops(8 * hw + sn), n1 = read_ops(8 * hw + sn + 1);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (nb >= tpos + 2 * (16 * hw + q4 + 4))
-                        four(cur, 16 * hw + q4, std::false_type{}, std::false_type{});
-                    else four(cur, 16 * hw + q4, std::true_type{}, std::false_type{});
-                    cur = nxt;
+                    sums(o[0]); sums(o[1]);
+                    const sp4 v = (s & 4) ? cd[2 * hw + 1] : cd[2 * hw];    // (selects, not indexed registers)
+                    sp_b3((s & 2) ? sp2{v.z, v.w} : sp2{v.x, v.y}, nk, u1, d1, u2, d2, u3, d3, b1, b2, b3);
+                    if (nb >= tpos + 4 * (8 * hw + s + 2)) {
+                        kstep(o[0], b1.x, b2.x, b3.x, std::false_type{});
+                        kstep(o[1], b1.y, b2.y, b3.y, std::false_type{});
+                    } else {
+                        kstep_checked(o[0], 8 * hw + s, b1.x, b2.x, b3.x);
+                        kstep_checked(o[1], 8 * hw + s + 1, b1.y, b2.y, b3.y);
+                    }
+                    o[0] = n0; o[1] = n1;
                 }
             }
         };
         half_tile(0, std::true_type{});
-        // second window of the tile: its entries were requested before the rows of the next
-        // tile, so waiting for them never waits for rows from HBM
-        store_code();
-        load_code(2 * tix + 2);
         half_tile(1, std::false_type{});
         // a span ends (its accumulators restart from C = 0 at the next span)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int n = 0; n < 2; ++n) tot[mt][n] = tot[mt][n] + acc[mt][n];
+        for (int mt = 0; mt < 2; ++mt) {
+            tot[mt][0] = tot[mt][0] + (k1[mt] - k3[mt]);
+            tot[mt][1] = tot[mt][1] + (k1[mt] + k2[mt]);
+        }
+        cd[0] = cdn[0]; cd[1] = cdn[1];
+        if (tix + 1 < kTiles) enter_tile(tix + 1);
     }
 }
+
+// A workgroup barrier that orders LDS traffic only.  __syncthreads() is a full workgroup fence: it
+// waits for every outstanding global load as well (s_waitcnt vmcnt(0)), and at the end of a unit the
+// rows of the NEXT unit's first tile are on their way -- each of the two barriers of the combine step
+// then cost one memory latency under load (~6 us; span_prof -DGPSMI_SPAN_STAMPS).  The sums the
+// waves exchange live in LDS, so only the LDS counter has to drain.
+__device__ __forceinline__ void sp_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// probe builds only (tools/probe/span_prof.hip): the 100 MHz clock at the phase boundaries of every
+// wave of the batch form, into a buffer nothing else reads
+#ifdef GPSMI_SPAN_STAMPS
+__device__ unsigned long long* g_span_stamps;
+#define SPAN_STAMP(i) do { if (lane == 0 && iter < 4 && blockIdx.x < 1024) g_span_stamps[(((size_t)blockIdx.x * 4 + iter) * 4 + wave) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define SPAN_STAMP(i) do {} while (0)
+#endif
 
 // ---- the kernels.  18.1 KiB of LDS per wave = eight waves per CU.
 //   batch form:        range = quarter; the four quarters of a block are the four waves of
@@ -530,14 +578,16 @@ __global__ __launch_bounds__(64 * WAVES, 2) void trk_span_kernel(
     const char* iq = static_cast<const char*>(iq_v);
     __shared__ __attribute__((aligned(16))) float lds[WAVES][kSpWaveFloats];
     __shared__ float4 ufac[kWholeBlock ? kSpCh * (NC + 1) : 1];      // (U[q], U[q+1]); .w = NaN: channel closed
+    __shared__ __attribute__((aligned(16))) float lo_close[kWholeBlock ? kSpCh * NC * 2 : 2];   // [channel][row][re, im]
+    __shared__ JobMid mids[2][kWholeBlock ? kSpCh : 1];             // descriptors of this unit and the next
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nunits = nblocks * ngroups;
     float* tl = &lds[wave][0];
-    sp4 st[16], tot[2][2], lo_fin[2][2];
-    bool all_lo[2];
-    int pb[2];
-    SpDesc md[2], smd;
+    sp4 st[16], tot[2][2];           // [M tile][re, im] of channel lane % 16
+    bool all_lo;
+    int pb;
+    SpDesc cmd;
 
     if (!kWholeBlock) {
         // ---- single-block form: one span per wave, raw sums to `rec`
@@ -548,117 +598,149 @@ __global__ __launch_bounds__(64 * WAVES, 2) void trk_span_kernel(
         const char* blk = iq + (size_t)b * kBlkBytes;
         const int pos0 = range * NSPANS * kSpTile;
         sp_load_tile<(DIAG & 8) ? 0 : 2, FMT>(blk, pos0, lane, st);   // before anything that depends on the descriptors
-        sp_wave_descs(mid + (size_t)b * P.nch + g * kSpCh, P.nch - g * kSpCh, lane, md, smd);
-        span_wave<NSPANS, FMT, DIAG>(blk, blk, kNowhere, tl, tl + kSpTileFloats, md, smd, code_eo, pos0, lane, st,
-                                     tot, lo_fin, all_lo, pb);
         float* o = rec + ((size_t)unit * kRanges + range) * kSpRecFloats + lane;
         const int rel0 = pos0 & (kSpQuarter - 1);
+        sp_wave_desc(mid + (size_t)b * P.nch + g * kSpCh, P.nch - g * kSpCh, lane, cmd);
+        sp4 lo_fin[2][2];                // what was summed below a boundary inside the span
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const bool closed = pb[n] > rel0 && pb[n] < rel0 + NSPANS * kSpTile;   // lo was closed in this range
+        for (int mt = 0; mt < 2; ++mt) { lo_fin[mt][0] = sp4{0.f, 0.f, 0.f, 0.f}; lo_fin[mt][1] = lo_fin[mt][0]; }
+        span_wave<NSPANS, FMT, DIAG>(blk, blk, kNowhere, tl, cmd, code_eo, pos0, lane, st, tot, all_lo, pb,
+                                     [&](int mt, sp4 re, sp4 im) { lo_fin[mt][0] = re; lo_fin[mt][1] = im; }, [] {});
+        // rec[unit][span][tot | lo_fin][M tile][re, im][v][lane = 16 (row group) + channel]
+        const bool closed = pb > rel0 && pb < rel0 + NSPANS * kSpTile;   // lo was closed in this range
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    o[((mt * 2 + n) * 4 + v) * 64] = tot[mt][n][v];
-                    if (closed) o[kSpLoOfs + ((mt * 2 + n) * 4 + v) * 64] = lo_fin[mt][n][v];
+                    o[((mt * 2 + p) * 4 + v) * 64] = tot[mt][p][v];
+                    if (closed) o[kSpLoOfs + ((mt * 2 + p) * 4 + v) * 64] = lo_fin[mt][p][v];
                 }
-        }
         return;
     }
 
-    // ---- batch form: the workgroup takes units blockIdx.x, blockIdx.x + gridDim.x, ...; the
-    // first rows and the descriptors of the next unit are requested before the combine step of
-    // the current one, so only the first unit of a workgroup waits for memory at its start
+    // ---- batch form: the workgroup takes units blockIdx.x, blockIdx.x + gridDim.x, ...
+    // Between the tile loops of two units nothing may wait for a global load: the rows of the next
+    // unit's first tile are requested by the last tile of this one, loads return in order, and a
+    // wait for anything younger is a wait for those 16 KiB at the latency of a loaded memory system
+    // (~6 us: span_prof -DGPSMI_SPAN_STAMPS showed 13 us per unit of set-up, barrier and combine
+    // phases made of such waits -- the descriptor fetch, spill reloads, a register of the replica
+    // entries reused as a temporary).  So: the descriptors of the next unit are fetched through the
+    // scalar cache at the START of this unit and parked in LDS behind the first tile's requests; the sums
+    // below a boundary go to LDS where the boundary passes (no registers held for them: no spills);
+    // the two barriers of the combine step order LDS traffic only.
     constexpr int kSumFloats = kSpCh * NC * 2;          // [channel][row][re, im]
     static_assert(2 * kSumFloats <= kSpTileFloats, "row sums must fit the tile area");
     constexpr int kItems = (kSpCh * (NC + 1) + 64 * WAVES - 1) / (64 * WAVES);
     int unit = blockIdx.x;
     if (unit >= nunits) return;
+    __builtin_amdgcn_s_setprio(3);
     const int pos0 = wave * kSpQuarter;
-    // for the combine step: which partial[q + 1] a thread writes, whether its channel is open
-    // and the row factors U[q], U[q+1].  The descriptor is fetched with the unit's others, the
-    // factors (double arithmetic) are formed at the start of the unit and wait in LDS: nothing
-    // of this stays in registers across the tile loop or is left for the tail of the block
-    bool on[kItems];
-    float om_item[kItems];
-    auto fetch_items = [&](int u) {
+    // a unit's descriptor of channel `cc` of the group (past the last channel: some valid one, to be
+    // marked closed by the caller once it has arrived -- nothing here may wait for the load)
+    auto mid_index = [&](int u, int cc) {
         const int g = u % ngroups, b = u / ngroups;
-#pragma unroll
-        for (int e = 0; e < kItems; ++e) {
-            const int item = (int)threadIdx.x + 64 * WAVES * e;
-            const int ci = g * kSpCh + item / (NC + 1);
-            on[e] = item < kSpCh * (NC + 1) && ci < P.nch;
-            const JobMid m2 = mid[b * P.nch + (on[e] ? ci : 0)];
-            on[e] = on[e] && m2.active;
-            om_item[e] = m2.om;
-        }
+        return (size_t)b * P.nch + (g * kSpCh + cc < P.nch ? g * kSpCh + cc : 0);
     };
-    auto park_items = [&]() {
+    auto mid_beyond = [&](int u, int cc) { return (u % ngroups) * kSpCh + cc >= P.nch; };
+    // the descriptors of unit `u` into mids[slot], through the SCALAR cache, three channels per wave:
+    // scalar loads have a counter of their own and wait for no row
+    constexpr int kPerWave = kSpCh / WAVES;
+    static_assert(kPerWave * WAVES == kSpCh, "the waves share the descriptor fetch evenly");
+    auto park_mids = [&](int u, int slot, int lane_w) {
 #pragma unroll
-        for (int e = 0; e < kItems; ++e) {
-            const int item = (int)threadIdx.x + 64 * WAVES * e;
-            if (item >= kSpCh * (NC + 1)) continue;
-            const int q = item % (NC + 1) - 1;
-            const float2 a0 = sp_row_factor(om_item[e], q), a1 = sp_row_factor(om_item[e], q + 1);
-            ufac[item] = make_float4(a0.x, a0.y, a1.x, on[e] ? a1.y : __builtin_nanf(""));
+        for (int i = 0; i < kPerWave; ++i) {
+            const int cc = wave * kPerWave + i;
+            const JobMid& src = mid[__builtin_amdgcn_readfirstlane((int)mid_index(u, cc))];
+            // (the fields as scalars: a uniform address alone did not keep the compiler from
+            // moving the loads under the one-lane store below as vector loads)
+            int f[5] = {src.delay_used, mid_beyond(u, cc) ? 0 : src.active, src.prn,
+                        __float_as_int(src.om), __float_as_int(src.ph)};
+#pragma unroll
+            for (int w = 0; w < 5; ++w) asm volatile("" : "+s"(f[w]));
+            if (lane_w == 0) {
+                JobMid m{};
+                m.delay_used = f[0]; m.active = f[1]; m.prn = f[2];
+                m.om = __int_as_float(f[3]); m.ph = __int_as_float(f[4]);
+                mids[slot][cc] = m;
+            }
         }
     };
     {
-        const int g = unit % ngroups, b = unit / ngroups;
-        sp_load_tile<(DIAG & 8) ? 0 : 2, FMT>(iq + (size_t)b * kBlkBytes, pos0, lane, st);
-        sp_wave_descs(mid + (size_t)b * P.nch + g * kSpCh, P.nch - g * kSpCh, lane, md, smd);
-        fetch_items(unit);
+        sp_load_tile<(DIAG & 8) ? 0 : 2, FMT>(iq + (size_t)(unit / ngroups) * kBlkBytes, pos0, lane, st);
+        for (int i = threadIdx.x; i < kSumFloats; i += 64 * WAVES) lo_close[i] = 0.f;
+        park_mids(unit, 0, lane);
+        __syncthreads();
     }
 #pragma unroll 1
-    for (;;) {
+    for (int iter = 0;; ++iter) {
         const int g = unit % ngroups, b = unit / ngroups;
-        park_items();
+        const int cur = iter & 1;
+        SPAN_STAMP(0);
         // (the lane-derived constants of a wave's set-up are recomputed per unit instead of
         // being carried through the tile loop in registers the loop needs)
         int lane_u = lane;
         asm volatile("" : "+v"(lane_u));
-        const char* blk = iq + (size_t)b * kBlkBytes;
         const int next = unit + (int)gridDim.x;
         const bool has_next = next < nunits;
+        // the row factors U[q], U[q+1] of the combine step (double arithmetic) are formed now and
+        // wait in LDS: nothing of this stays in registers across the tile loop or is left for the
+        // tail of the block
+#pragma unroll
+        for (int e = 0; e < kItems; ++e) {
+            const int item = (int)threadIdx.x + 64 * WAVES * e;
+            if (item >= kSpCh * (NC + 1)) continue;
+            const JobMid& m2 = mids[cur][item / (NC + 1)];
+            const int q = item % (NC + 1) - 1;
+            const float2 a0 = sp_row_factor(m2.om, q), a1 = sp_row_factor(m2.om, q + 1);
+            ufac[item] = make_float4(a0.x, a0.y, a1.x, m2.active ? a1.y : __builtin_nanf(""));
+        }
+        {
+            const int c = lane_u & 15;
+            const JobMid& m = mids[cur][c < kSpCh ? c : 0];
+            cmd.delay_used = m.delay_used; cmd.active = c < kSpCh && m.active; cmd.prn = m.prn; cmd.om = m.om; cmd.ph = m.ph;
+        }
+        SPAN_STAMP(1);
+        // Everything outside the tile loop runs at raised priority: a wave in its set-up or combine
+        // phase shares its SIMD with a wave that issues one fp32 MFMA after the other
+        __builtin_amdgcn_s_setprio(0);
+        const char* blk = iq + (size_t)b * kBlkBytes;
         const char* next_blk = has_next ? iq + (size_t)(next / ngroups) * kBlkBytes : blk;
-        span_wave<NSPANS, FMT, DIAG>(blk, next_blk, has_next ? pos0 : kNowhere, tl, tl + kSpTileFloats, md, smd, code_eo,
-                                pos0, lane_u, st, tot, lo_fin, all_lo, pb);
+        span_wave<NSPANS, FMT, DIAG>(
+            blk, next_blk, has_next ? pos0 : kNowhere, tl, cmd, code_eo, pos0, lane_u, st, tot, all_lo, pb,
+            [&](int mt, sp4 re, sp4 im) {              // below a boundary: rows 16 mt + 4 (lane / 16) + v of the channel
+                float* dst = lo_close + ((lane_u & 15) * NC + 16 * mt + 4 * (lane_u >> 4)) * 2;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) *reinterpret_cast<sp2*>(dst + 2 * v) = sp2{re[v], im[v]};
+            },
+            [&] { if (has_next) park_mids(next, cur ^ 1, lane_u); });   // behind the first tile's requests
+        __builtin_amdgcn_s_setprio(3);
+        SPAN_STAMP(2);
         // the hi / lo sums of every row of the quarter into LDS (the wave's own tile area),
-        // D[i = 4 (lane / 16) + v][j = lane % 16]
+        // D[i = 4 (lane / 16) + v][j = lane % 16]; a quarter that lies below the delay altogether
+        // is lo, one that holds the boundary has left its lo part in lo_close
         if (!(DIAG & 4)) {
             float* hi = tl;
             float* lo = tl + kSumFloats;
-            const int j = lane & 15, part = j & 1;
+            const int c = lane & 15;
+            if (c < kSpCh) {
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const int c = 8 * n + (j >> 1);
-                const sp4 z = sp4{0.f, 0.f, 0.f, 0.f};
+                for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const sp4 w_hi = all_lo[n] ? z : tot[mt][n];
-                    const sp4 w_lo = all_lo[n] ? tot[mt][n] : lo_fin[mt][n];
-                    if (c < kSpCh) {
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            const int row = 16 * mt + 4 * (lane >> 4) + v;
-                            hi[(c * NC + row) * 2 + part] = w_hi[v];
-                            lo[(c * NC + row) * 2 + part] = w_lo[v];
-                        }
+                    for (int v = 0; v < 4; ++v) {
+                        const int row = 16 * mt + 4 * (lane >> 4) + v;
+                        const sp2 t = sp2{tot[mt][0][v], tot[mt][1][v]}, z = sp2{0.f, 0.f};
+                        *reinterpret_cast<sp2*>(hi + (c * NC + row) * 2) = all_lo ? z : t;
+                        *reinterpret_cast<sp2*>(lo + (c * NC + row) * 2) = all_lo ? t : z;
                     }
-                }
             }
-        }
-        // the descriptors of the next unit on their way while the quarters are combined
-        if (has_next) {
-            sp_wave_descs(mid + (size_t)(next / ngroups) * P.nch + (next % ngroups) * kSpCh,
-                          P.nch - (next % ngroups) * kSpCh, lane, md, smd);
-            fetch_items(next);
-        }
-        if (!(DIAG & 4)) {
-            // behind one barrier all threads add the quarters in their fixed order, apply U and
-            // write partial[q + 1], q = -1 .. 31
-            __syncthreads();
+            // behind one barrier all threads add the quarters in their fixed order (the lo part of
+            // the quarter with the boundary comes after the quarters below it and before zeros: at
+            // the end), apply U and write partial[q + 1], q = -1 .. 31
+            SPAN_STAMP(3);
+            sp_lds_barrier();
+            SPAN_STAMP(4);
 #pragma unroll
             for (int e = 0; e < kItems; ++e) {
                 const int item = (int)threadIdx.x + 64 * WAVES * e;
@@ -669,21 +751,29 @@ __global__ __launch_bounds__(64 * WAVES, 2) void trk_span_kernel(
                 float hx = 0.f, hy = 0.f, lx = 0.f, ly = 0.f;
 #pragma unroll
                 for (int w = 0; w < WAVES; ++w) {
-                    const float* hi = &lds[w][0];
-                    const float* lo = hi + kSumFloats;
-                    if (q >= 0) { hx += hi[(cc * NC + q) * 2]; hy += hi[(cc * NC + q) * 2 + 1]; }
-                    if (q + 1 < NC) { lx += lo[(cc * NC + q + 1) * 2]; ly += lo[(cc * NC + q + 1) * 2 + 1]; }
+                    const float* hi_w = &lds[w][0];
+                    const float* lo_w = hi_w + kSumFloats;
+                    if (q >= 0) { hx += hi_w[(cc * NC + q) * 2]; hy += hi_w[(cc * NC + q) * 2 + 1]; }
+                    if (q + 1 < NC) { lx += lo_w[(cc * NC + q + 1) * 2]; ly += lo_w[(cc * NC + q + 1) * 2 + 1]; }
+                }
+                if (q + 1 < NC) {
+                    sp2* lc = reinterpret_cast<sp2*>(lo_close + (cc * NC + q + 1) * 2);
+                    const sp2 v = *lc;
+                    lx += v.x; ly += v.y;
+                    *lc = sp2{0.f, 0.f};                    // (this thread is its only reader: free for the next unit)
                 }
                 partial[((size_t)b * P.nch + g * kSpCh + cc) * (NC + 1) + o] =
                     sp_window(hx, hy, lx, ly, make_float2(uf.x, uf.y), make_float2(uf.z, uf.w));
             }
         }
         if (DIAG & 4) {                                  // (probe: keep the sums alive without the combine step)
-            if (tot[0][0][0] + tot[0][1][1] + tot[1][0][2] + tot[1][1][3] + lo_fin[0][0][0] + lo_fin[1][1][1] == 123.456f)
-                partial[(size_t)unit * 64 + lane] = make_float2(tot[0][0][0], lo_fin[1][1][1]);
+            if (tot[0][0][0] + tot[0][1][1] + tot[1][0][2] + tot[1][1][3] == 123.456f)
+                partial[(size_t)unit * 64 + lane] = make_float2(tot[0][0][0], tot[1][1][1]);
         }
+        SPAN_STAMP(5);
         if (!has_next) break;
-        if (!(DIAG & 4)) __syncthreads();               // the tile areas are free again
+        if (!(DIAG & 4)) sp_lds_barrier();              // the tile areas, ufac and mids[cur] are free again
+        SPAN_STAMP(6);
         unit = next;
     }
 }
@@ -699,7 +789,8 @@ __device__ __forceinline__ void span_collect_quarter(const float* __restrict__ r
     constexpr int kLen = NSPANS * kSpTile;                   // positions per record
     const int g = cidx / kSpCh, cc = cidx % kSpCh;
     const int r = lane >> 1, part = lane & 1;
-    const int n = cc >> 3, j = 2 * (cc & 7) + part, mt = r >> 4, rg = (r & 15) >> 2, v = r & 3;
+    const int mt = r >> 4, rg = (r & 15) >> 2, v = r & 3;
+    const int n = part, j = cc;                        // [M tile][re, im][v][16 (row group) + channel]
     const float* src = rec + ((size_t)(b * ngroups + g) * (4 * kPerQ) + (size_t)kPerQ * Q) * kSpRecFloats
                        + ((mt * 2 + n) * 4 + v) * 64 + 16 * rg + j;
     const int rel = d - Q * kSpQuarter;

@@ -59,6 +59,9 @@ __global__ void collect_kernel(const float* rec, const JobMid* mid, int ngroups,
     if (lane <= 32) partial[(size_t)job * 33 + lane] = S[wave][lane];
 }
 
+#ifdef GPSMI_SPAN_STAMPS
+static unsigned long long* g_stamp_buf;
+#endif
 template <int NSP, int WAVES, int DIAG>
 static void launch_span_t(const Bufs& B, int nblocks, int nch, bool collect) {
     TrkParams P{};
@@ -245,10 +248,11 @@ int main(int argc, char** argv) {
             const float v = p == 0 ? 0.f : ((hsh >> 13) & 1 ? 1.f : -1.f) * (((hsh >> 20) & 3) ? 1.f : 0.3f + (hsh >> 24) * 0.002f);
             code2[(size_t)p * 4096 + i] = code2[(size_t)p * 4096 + 2048 + i] = v;
         }
-    for (int p = 0; p <= GPSMI_MAX_PRN; ++p)
-        for (int e = 0; e < 2; ++e)
-            for (int s = 0; s < 2048; ++s)
-                eo[(size_t)p * 4096 + e * 2048 + s] = code2[(size_t)p * 4096 + 2 * (s % 1024) + e];
+    for (int p = 0; p <= GPSMI_MAX_PRN; ++p) {
+        for (int e = 0; e < 4; ++e)
+            for (int s = 0; s < 1024; ++s)
+                eo[(size_t)p * 4096 + e * 1024 + s] = code2[(size_t)p * 4096 + (4 * s + e) % 2048];
+    }
     hipMalloc((void**)&B.code2, code2.size() * 4);
     hipMemcpy(B.code2, code2.data(), code2.size() * 4, hipMemcpyHostToDevice);
     hipMalloc((void**)&B.code_eo, eo.size() * 4);
@@ -256,6 +260,13 @@ int main(int argc, char** argv) {
     hipMalloc((void**)&B.partial, (size_t)nblocks * nch * 33 * sizeof(float2));
     hipMalloc((void**)&B.ref, (size_t)64 * nch * 33 * 16);
     hipMalloc((void**)&B.rec, (size_t)std::max(nblocks * 4, 32 * 32) * kSpRecFloats * sizeof(float));
+#ifdef GPSMI_SPAN_STAMPS
+    {   // every launch of the batch form writes its stamps: the buffer exists before the first one
+        // (up to 1024 workgroups x 4 units x 4 waves x 8 stamps)
+        hipMalloc((void**)&g_stamp_buf, (size_t)1024 * 4 * 4 * 8 * 8);
+        hipMemcpyToSymbol(HIP_SYMBOL(g_span_stamps), &g_stamp_buf, sizeof(g_stamp_buf));
+    }
+#endif
 
     const int ncheck = std::min(nblocks, 24);   // (<= 32: the record buffer holds 32 x 32 records)
     for (int mode = 0; mode < 4; ++mode) {
@@ -274,6 +285,63 @@ int main(int argc, char** argv) {
             printf("batch form == single-block form: %s\n", memcmp(a.data(), c.data(), a.size() * 8) ? "NO" : "yes");
         }
     }
+#ifdef GPSMI_SPAN_STAMPS
+    {   // phase stamps of the batch form (build with -DGPSMI_SPAN_STAMPS): per wave and unit,
+        // 0 unit start, 1 row factors parked, 2 tiles done, 3 sums in LDS, 4 past the first barrier,
+        // 5 combined, 6 past the second barrier; 100 MHz ticks
+        set_delays(B, nblocks, nch, 0);
+        const int grid = std::min(nblocks, g_slots);
+        const size_t nst = (size_t)grid * 4 * 4 * 8;
+        unsigned long long* d_st = g_stamp_buf;
+        for (int i = 0; i < 20; ++i) launch_span(B, nblocks, nch);
+        hipDeviceSynchronize();
+        hipMemset(d_st, 0, nst * 8);
+        launch_span(B, nblocks, nch);
+        hipDeviceSynchronize();
+        std::vector<unsigned long long> st(nst);
+        hipMemcpy(st.data(), d_st, nst * 8, hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (auto v : st) if (v) { t0 = std::min(t0, v); t1 = std::max(t1, v); }
+        printf("-- stamps: kernel spans %.2f us (first to last stamp), %d workgroups\n", (t1 - t0) * 0.01, grid);
+        const int iters = (nblocks + grid - 1) / grid;
+        for (int it = 0; it < iters && it < 4; ++it) {
+            double ph[7] = {0}, wait1 = 0, spread = 0, start_min = 1e30, start_max = 0, end_min = 1e30, end_max = 0;
+            int n = 0;
+            for (int wg = 0; wg < grid; ++wg) {
+                const unsigned long long* w0 = &st[(((size_t)wg * 4 + it) * 4) * 8];
+                if (!w0[0]) continue;
+                unsigned long long tmin = ~0ull, tmax = 0;
+                for (int w = 0; w < 4; ++w) {
+                    const unsigned long long* q = w0 + w * 8;
+                    for (int i = 0; i < 6; ++i) if (q[i + 1]) ph[i] += (double)(q[i + 1] - q[i]);
+                    tmin = std::min(tmin, q[2]); tmax = std::max(tmax, q[2]);
+                    wait1 += (double)(q[4] - q[3]);
+                    start_min = std::min(start_min, (double)(q[0] - t0)); start_max = std::max(start_max, (double)(q[0] - t0));
+                    end_min = std::min(end_min, (double)(q[5] - t0)); end_max = std::max(end_max, (double)(q[5] - t0));
+                }
+                spread += (double)(tmax - tmin);
+                ++n;
+            }
+            if (!n) continue;
+            printf("   unit %d of a workgroup (%d workgroups): park %.2f  tiles %.2f  sums->LDS %.2f  barrier wait %.2f  combine %.2f  second barrier %.2f us per wave;"
+                   "  spread of 'tiles done' inside a workgroup %.2f us;  starts %.1f..%.1f  ends %.1f..%.1f us\n",
+                   it, n, ph[0] / (4 * n) * 0.01, ph[1] / (4 * n) * 0.01, ph[2] / (4 * n) * 0.01, ph[3] / (4 * n) * 0.01,
+                   ph[4] / (4 * n) * 0.01, ph[5] / (4 * n) * 0.01, spread / n * 0.01, start_min * 0.01, start_max * 0.01,
+                   end_min * 0.01, end_max * 0.01);
+        }
+        // how many waves are inside the tile loop at each microsecond
+        std::vector<int> busy((size_t)((t1 - t0) / 100 + 2), 0);
+        for (size_t r = 0; r < nst / 8; ++r) {
+            const unsigned long long* q = &st[r * 8];
+            if (!q[0] || !q[2]) continue;
+            for (unsigned long long t = (q[1] - t0) / 100; t <= (q[2] - t0) / 100; ++t) busy[t]++;
+        }
+        printf("   waves inside the tile loop per us:");
+        for (size_t t = 0; t < busy.size(); ++t) printf(" %d", busy[t]);
+        printf("\n");
+        return 0;
+    }
+#endif
     for (int mode : {0, 2}) {
         set_delays(B, nblocks, nch, mode);
         printf("-- delays: %s\n", mode == 0 ? "spread" : "one quarter");
