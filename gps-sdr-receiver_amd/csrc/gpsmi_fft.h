@@ -21,6 +21,18 @@
 
 namespace gpsmi {
 
+// A workgroup barrier that orders LDS traffic only.  __syncthreads() is a full workgroup fence: it
+// also waits for every outstanding global load (s_waitcnt vmcnt(0)), so a load issued ahead of a
+// transform to hide its latency behind it -- the replica spectrum of the code-phase correlation, the
+// rows of a pipelined fold, the first tile of a correlator's next unit -- would be waited for at the
+// transform's first barrier.  What the threads of these kernels exchange lives in LDS: only the LDS
+// counter has to drain.  (Values loaded from global memory are still waited for where they are
+// used: the compiler tracks that per register.)
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+
 constexpr int kFftN = 2048;
 constexpr int kFftThreads = 256;
 constexpr int kFftPlane = kFftN + kFftN / 32;         // buffer 0, complex elements
@@ -145,7 +157,7 @@ __device__ __forceinline__ void fft2048(float2* vio, float* lds, const FftTw& tw
     dft8p(v);
 #pragma unroll
     for (int r = 0; r < 8; ++r) buf0[fft_pad(8 * t + r)] = v[r];
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] = buf0[fft_pad(t + 256 * r)];
     // pass 2: Ns = 8, twiddle exp(-2 pi i r k / 64), out (t/8)*64 + k + 8 r
@@ -158,7 +170,7 @@ __device__ __forceinline__ void fft2048(float2* vio, float* lds, const FftTw& tw
 #pragma unroll
         for (int r = 0; r < 8; ++r) buf1[fft_pad1(base + 8 * r)] = v[r];
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] = buf1[fft_pad1(t + 256 * r)];
     // pass 3: Ns = 64, twiddle exp(-2 pi i r k / 512), out (t/64)*512 + k + 64 r
@@ -171,7 +183,7 @@ __device__ __forceinline__ void fft2048(float2* vio, float* lds, const FftTw& tw
 #pragma unroll
         for (int r = 0; r < 8; ++r) buf0[fft_pad(base + 64 * r)] = v[r];
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] = buf0[fft_pad(t + 256 * r)];
     // pass 4: Ns = 512, radix 4, two butterflies per thread (j = t, t + 256);

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(kPfaThreads) void pfa_corr_kernel(
         sincospif(2.0f * (float)(t - 32) / 31.0f, &sn, &cs);
         trig31[t - 32] = fft_c{cs, sn};
     }
-    __syncthreads();
+    lds_barrier();
     fft_c nx[16];                                 // MODE 0: the samples of `cell`, requested one cell ahead
     // (buffer loads: one scalar base per cell, ONE lane offset for the sixteen loads, the row
     // distance in the instruction's scalar offset -- sixteen 64-bit lane addresses would not fit
@@ -278,12 +278,12 @@ __global__ __launch_bounds__(kPfaThreads) void pfa_corr_kernel(
     asm volatile("" : "+v"(t_opaque));
     const int t = t_opaque, wave = t >> 6, lane = t & 63;
     const int sig = pfa_sigma(t < kPfaC ? t : 0);
-    __syncthreads();
+    lds_barrier();
     PFA_STAMP(1);
 
     // ---- P2: Z_3 x Z_11
     if (t < kPfaSlabs33) pfa_slab33(data + (t / 31) * kPfaPitch + (t % 31));
-    __syncthreads();
+    lds_barrier();
     PFA_STAMP(2);
 
     // ---- P3: Z_31, x conj(replica spectrum), Z_31 again
@@ -371,12 +371,12 @@ __global__ __launch_bounds__(kPfaThreads) void pfa_corr_kernel(
             __builtin_amdgcn_wave_barrier();
         }
     }
-    __syncthreads();
+    lds_barrier();
     PFA_STAMP(3);
 
     // ---- P4: Z_3 x Z_11 on the way back
     if (t < kPfaSlabs33) pfa_slab33(data + (t / 31) * kPfaPitch + (t % 31));
-    __syncthreads();
+    lds_barrier();
     PFA_STAMP(4);
 
     // ---- P5: coordinate twiddle, FFT-16, magnitudes at lag n = t + 1023 j, statistics.
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(kPfaThreads) void pfa_corr_kernel(
     s2 = wave_sum_dpp(s2);
     wave_argmax_dpp(bv, bi);
     if (lane == 0) { red_s[wave] = sm; red_d[wave] = s2; red_v[wave] = bv; red_i[wave] = bi; }
-    __syncthreads();
+    lds_barrier();
     if (t == 0) {
         double dsm = 0.0, ds2 = 0.0;
         bv = red_v[0]; bi = red_i[0];
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(kPfaThreads) void pfa_corr_kernel(
         r.hi = data[(nhi / kPfaC) * kPfaPitch + pfa_sigma(nhi % kPfaC)].x;
         out[cell] = r;
     }
-    __syncthreads();                              // (the neighbours are read: the next cell may write `data`)
+    lds_barrier();                              // (the neighbours are read: the next cell may write `data`)
     PFA_STAMP(6);
     cell += MODE == 0 ? (int)gridDim.x : 1;
     if (cell >= cell_end) break;

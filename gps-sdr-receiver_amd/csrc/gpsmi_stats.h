@@ -6,6 +6,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "gpsmi_fft.h"
+
 namespace gpsmi {
 
 template <int CTRL, int ROWS>
@@ -77,7 +79,7 @@ __device__ __forceinline__ void corr_stats8(const float* mag, int t, float* magb
     sm = wave_sum_dpp(sm);
     wave_argmax_dpp(bv, bi);
     if (lane == 0) { red[wave] = sm; red[4 + wave] = bv; ((int*)red)[8 + wave] = bi; }
-    __syncthreads();
+    lds_barrier();
     sm = (red[0] + red[1]) + (red[2] + red[3]);
     bv = red[4]; bi = ((int*)red)[8];
 #pragma unroll
@@ -92,7 +94,7 @@ __device__ __forceinline__ void corr_stats8(const float* mag, int t, float* magb
     for (int q = 0; q < 8; ++q) { const float d = mag[q] - mean; d2 += d * d; }
     d2 = wave_sum_dpp(d2);
     if (lane == 0) red[12 + wave] = d2;
-    __syncthreads();
+    lds_barrier();
     d2 = (red[12] + red[13]) + (red[14] + red[15]);
     sd = sqrtf(d2 * (1.0f / N));
     amax = bi;

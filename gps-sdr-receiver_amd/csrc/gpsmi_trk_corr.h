@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256, (CG > 4 || CG == 1) ? 2 : 3) void trk_corr_ker
             }
         }
     }
-    __syncthreads();
+    lds_barrier();                     // (the rows requested above stay in flight)
 
     // ---- fold: acc[c][r] = sum_i U[c][i] x[i][t + 256 r]
     v2f acc[CG][8];
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256, (CG > 4 || CG == 1) ? 2 : 3) void trk_corr_ker
         prepare(c, s, v, rs);
         fft2048(v, lds, ftw, t);
         times_conj(v, rs);
-        __syncthreads();
+        lds_barrier();
         fft2048(v, lds, ftw, t);
         float mag[8];
         magnitudes(v, mag);

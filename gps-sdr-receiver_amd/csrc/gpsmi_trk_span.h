@@ -522,15 +522,6 @@ __device__ __forceinline__ void span_wave(const void* __restrict__ blk, const vo
     }
 }
 
-// A workgroup barrier that orders LDS traffic only.  __syncthreads() is a full workgroup fence: it
-// waits for every outstanding global load as well (s_waitcnt vmcnt(0)), and at the end of a unit the
-// rows of the NEXT unit's first tile are on their way -- each of the two barriers of the combine step
-// then cost one memory latency under load (~6 us; span_prof -DGPSMI_SPAN_STAMPS).  The sums the
-// waves exchange live in LDS, so only the LDS counter has to drain.
-__device__ __forceinline__ void sp_lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 // probe builds only (tools/probe/span_prof.hip): the 100 MHz clock at the phase boundaries of every
 // wave of the batch form, into a buffer nothing else reads
 #ifdef GPSMI_SPAN_STAMPS
@@ -739,7 +730,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void trk_span_kernel(
             // the quarter with the boundary comes after the quarters below it and before zeros: at
             // the end), apply U and write partial[q + 1], q = -1 .. 31
             SPAN_STAMP(3);
-            sp_lds_barrier();
+            lds_barrier();
             SPAN_STAMP(4);
 #pragma unroll
             for (int e = 0; e < kItems; ++e) {
@@ -772,7 +763,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void trk_span_kernel(
         }
         SPAN_STAMP(5);
         if (!has_next) break;
-        if (!(DIAG & 4)) sp_lds_barrier();              // the tile areas, ufac and mids[cur] are free again
+        if (!(DIAG & 4)) lds_barrier();              // the tile areas, ufac and mids[cur] are free again
         SPAN_STAMP(6);
         unit = next;
     }
