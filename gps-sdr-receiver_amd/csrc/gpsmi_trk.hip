@@ -476,8 +476,10 @@ struct gpsmi_trk {
                                      // (gpsmi_trk_span.h); 3 = the round-1 32x32x2 form, four waves per
                                      // workgroup, three workgroups per CU
     float* d_code2 = nullptr;        // [GPSMI_MAX_PRN + 1][2 cs]: replica twice (no index wrap)
-    float* d_code_eo = nullptr;      // [GPSMI_MAX_PRN + 1][2][cs]: replica split by index parity, each
-                                     // plane twice (span form)
+    float* d_code_eo = nullptr;      // [GPSMI_MAX_PRN + 1][...]: the replica re-cut for the matrix correlators.  Span form
+                                     // (2048): four planes by index mod 4, entry h of plane e = replica[(4 h + e) mod 2048],
+                                     // 1024 entries each (a lane's run never wraps); span8 form: two planes by index
+                                     // parity, each twice over
     int n_cu = 256;                  // compute units of the device
     int iq_fmt = GPSMI_IQ_C64;       // what the iq pointers of process / replay point to
     int nchunks = 1;                 // spans of 256 * stream_j positions per code period

@@ -7,41 +7,47 @@
 //       positions; 256-byte segments top out at 5.2 TB/s, 512-byte ones reach 5.7-6.0,
 //       tools/probe/tile_read.hip),
 //   (2) a batch of 1024 blocks is two full rounds of workgroups (two workgroups of four
-//       waves per CU, 18 KiB of LDS per wave) with no one-wave-per-SIMD tail, and the waves
-//       of a workgroup never wait for each other (no barrier: each writes its own sums),
+//       waves per CU, 16.3 KiB of LDS per wave) with no one-wave-per-SIMD tail,
 //   (3) the order of the float32 sums is defined by the DATA, not by the launch: a block
-//       is cut into 32 SPANS of 64 positions; a span is summed position by position, the
-//       spans of a quarter (512 positions) are added in order, then the four quarters.
-//       Any assignment of spans to waves that follows this order gives the same bits:
-//       the batch form gives a wave a quarter (eight spans), the single-block form gives
+//       is cut into 32 SPANS of 64 positions; a span is summed K-step by K-step (four
+//       positions), the spans of a quarter (512 positions) are added in order, then the four
+//       quarters.  Any assignment of spans to waves that follows this order gives the same
+//       bits: the batch form gives a wave a quarter (eight spans), the single-block form gives
 //       every span its own wave (32 waves on up to 32 CUs instead of 4 waves on one).
 //
-//   v_mfma_f32_16x16x4_f32, D[16 x 16] += A[16 x 4] B[4 x 16] for one PAIR of positions:
-//     M = 16 code periods (two M tiles = the 32 rows of the block),
-//     K = (position parity pi, re/im kappa) of the samples at positions 2 q + pi,
-//     N = (channel, re/im) for 8 channels; two N tiles = up to 16 channels (12 are staged):
-//       A[r][(pi, kappa)]      = x[r][2 q + pi].{re, im}
-//       B[(pi, 0)][(c, re)] =  B_re,  B[(pi, 1)][(c, re)] = -B_im,
-//       B[(pi, 0)][(c, im)] =  B_im,  B[(pi, 1)][(c, im)] =  B_re,
-//       B_c(m) = replica_c[(m - d_c) mod 2048] * exp(-j theta_c(m)),  m = 2 q + pi.
-//   The fp32 MFMA runs on the SIMD's own fp32 lanes: no other VALU instruction issues
-//   meanwhile, so every VALU / LDS instruction between two MFMAs adds to the SIMD's time.
-//   B is therefore built once per pair for all 32 rows: a lane holds one real component u
-//   of the carrier phasor for its two channels (one per N tile) at positions m, m + 2 in a
-//   packed register pair and advances both by four positions with the coupled recurrence
-//   dl -= kappa u, u += dl (kappa = 4 sin^2(2 phi)), twelve packed instructions per four
-//   pairs in one asm block (no wait states before the MFMAs that read B).  The exact phasor
-//   is taken at the start of every quarter only (128 steps, as far as the recurrence stays
-//   accurate); a wave that starts at a later span of the quarter runs the same recurrence
-//   from the quarter start without the MFMAs, so it forms the same bits.  The replica
-//   samples come from a table split by index parity (a lane's positions all have the same
-//   parity), staged through LDS 32 positions at a time.
+// THREE real products per complex one (round 3; the round-2 form spent four).  With
+// x = a + j b and B = c + j d,
+//     P1 = (a + b) c,   P2 = a (d - c),   P3 = b (c + d):   re = P1 - P3,  im = P1 + P2,
+// so a K-step of FOUR positions is three real matrix products on v_mfma_f32_16x16x4_f32,
+// D[16 x 16] += A[16 x 4] B[4 x 16], with M = 16 code periods (two M tiles = the 32 rows of the
+// block), K = four positions, N = channel (12 of 16 columns; the four-product form had
+// N = (channel, re/im) and K = (position pair, re/im)): 96 MFMAs per tile instead of 128.
+//     A[r][k]  = (a + b | a | b) of x[r][4 s + k],        lane = (row r = lane % 16, k = lane / 16)
+//     B[k][c]  = replica_c[(m - d_c) mod 2048] * (u1 | u2 | u3)_c(m), m = 4 s + k, lane = (c, k)
+//     D[r][c]  = three accumulators k1, k2, k3 per M tile, lane = (c, row group)
+// The fp32 MFMA runs on the SIMD's own fp32 lanes: no other VALU instruction issues
+// meanwhile, so every VALU instruction between two MFMAs adds to the SIMD's time.  The three
+// B components (z.re, z.im - z.re, z.re + z.im of the carrier phasor z = exp(-j theta)) are
+// linear in (cos, sin), so each follows the same coupled recurrence dl -= kappa u, u += dl:
+// a lane holds them for ITS channel at positions m, m + 4 in packed register pairs and advances
+// eight positions per step (kappa = 4 sin^2(4 phi)): nine packed instructions per two K-steps
+// (twelve MFMAs) in one asm block, plus one v_add_f32 per A operand for a + b.  The exact
+// phasor is taken at the start of every quarter only (64 steps, as far as the recurrence stays
+// accurate); a wave that starts at a later span of the quarter runs the same recurrence from
+// the quarter start without the MFMAs, so it forms the same bits.  The replica comes straight
+// from a table split by index mod 4 (a lane's positions are 4 apart): 16 consecutive entries
+// per lane and tile, no LDS stage.
 //
 // Window q of the reference = positions m >= d of row q ("hi") plus m < d of row q+1
-// ("lo").  Where the boundary d_c falls inside a wave's range the four lanes of channel c
-// close the lo sum (lo = sum so far) and restart; a pair of positions that straddles an odd
-// d_c is issued twice with B masked.  Only the group of four pairs that holds a boundary
-// takes that path; everything else runs 16 MFMAs per group straight.
+// ("lo").  Where the boundary d_c falls inside a wave's range the lanes of channel c close the
+// lo sum (lo = sum so far) and restart; a K-step that holds a boundary is issued in pieces with
+// B masked to the positions of the piece.  Only the half tile that holds a boundary takes that
+// (rolled) path; everything else runs 48 MFMAs per half tile straight.
+//
+// What bounds the batch form now is the memory system (16 KiB in flight per wave at ~6 us of
+// latency under load), so nothing outside the tile loop may wait for a global load: see the
+// comments at sp_swap_tile, in span_wave (where the replica entries are requested) and at the
+// batch form of the kernel (scalar descriptor fetch, LDS-only barriers, lo sums parked in LDS).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -50,14 +56,11 @@
 
 namespace gpsmi {
 
-constexpr int kSpCh = 12;                      // channels per workgroup (staged through LDS)
+constexpr int kSpCh = 12;                      // channels per workgroup (of the 16 columns of an MFMA)
 constexpr int kSpTile = 64;                    // positions per tile = per span (unit of the summation order)
 constexpr int kSpQuarter = 512;                // positions per quarter (eight spans)
 constexpr int kSpRowDw = 2 * kSpTile + 2;      // dwords per tile row: lane = (row, k) reads are conflict-free
 constexpr int kSpTileFloats = 32 * kSpRowDw;
-constexpr int kSpWin = 32;                     // positions per replica window
-constexpr int kSpCodePitch = kSpWin / 2 + 4;   // floats per (channel, parity) row of a window
-constexpr int kSpCodeFloats = kSpCh * 2 * kSpCodePitch;
 constexpr int kSpWaveFloats = kSpTileFloats;                     // 4160 floats = 16,640 B per wave
 constexpr int kSpInf = 1 << 20;
 
@@ -531,15 +534,15 @@ __device__ unsigned long long* g_span_stamps;
 #define SPAN_STAMP(i) do {} while (0)
 #endif
 
-// ---- the kernels.  18.1 KiB of LDS per wave = eight waves per CU.
+// ---- the kernels.  16.3 KiB of LDS per wave (+ 10 KiB per workgroup of the batch form) = eight waves per CU.
 //   batch form:        range = quarter; the four quarters of a block are the four waves of
 //                      one workgroup (so the four 4 KiB pieces of every 16 KiB row are
 //                      requested together).  The waves leave their hi / lo row sums in LDS;
-//                      behind a barrier all threads add the quarters in their fixed order and
-//                      write partial[job][.] (3 KiB per block).  The workgroups are
-//                      persistent (two per CU, each takes every gridDim-th block): the
-//                      first rows and the descriptors of the next block are requested before
-//                      the combine step of the current one.
+//                      behind an (LDS-only) barrier all threads add the quarters in their fixed
+//                      order and write partial[job][.] (3 KiB per block).  The workgroups are
+//                      persistent (two per CU, each takes every gridDim-th block): the first
+//                      rows of the next block are requested by the last tile of this one, its
+//                      descriptors wait in LDS since the start of this one.
 //                      Measured instead, per 1024-block launch: the wave that arrives last
 //                      combines alone, the others exit without a barrier +6 us (the
 //                      workgroup's LDS is held until that wave is done); one-wave workgroups
@@ -548,7 +551,7 @@ __device__ unsigned long long* g_span_stamps;
 //                      a launch too small to fill the CUs with quarters (the closed loop).
 //                      A wave writes the raw sums of its span (tot always, lo_fin by the
 //                      lanes whose boundary lay inside it) to `rec`, 2048 floats per wave:
-//                        rec[unit = b * ngroups + g][span][tot | lo_fin][M tile][N tile][v][lane]
+//                        rec[unit = b * ngroups + g][span][tot | lo_fin][M tile][re, im][v][lane = 16 (row group) + channel]
 //                      and span_collect (called by the epilogue kernel) adds the spans of a
 //                      block up in the order the batch form uses: same bits.
 constexpr int kSpRecFloats = 2 * 16 * 64;              // one wave's record

@@ -14,7 +14,7 @@ names = {'bench_line.json': 'bench_line.json', 'bench_prof_line.json': 'bench_li
          'acq_bench.txt': 'acq_bench.txt', 'batched_bench.txt': 'batched_bench.txt',
          'stream_bench.txt': 'stream_bench.txt', 'cfg5_kernel_table.md': 'cfg5_kernel_table.md',
          'cfg5_line.json': 'cfg5_line.json', 'clock_settling.txt': 'clock_settling.txt',
-         'chain_floor.txt': 'chain_floor.txt'}
+         'chain_floor.txt': 'chain_floor.txt', 'span_stamps.txt': 'span_stamps.txt'}
 for src, dst in names.items():
     if os.path.exists(R + src):
         shutil.copy(R + src, P + dst)

@@ -39,6 +39,7 @@ rm -rf $out/pmc
 fi
 if [ $part = rest ] || [ $part = all ]; then
 tools/probe/span_prof 1024 > $out/span_prof.txt 2>&1 || echo "span_prof failed"
+(tools/probe/span_stamps 1024 | tail -5) > $out/span_stamps.txt 2>&1 || echo "span_stamps failed"
 tools/probe/pfa_prof 6144 > $out/pfa_prof.txt 2>&1 || echo "pfa_prof failed"
 tools/probe/chain_floor > $out/chain_floor.txt 2>&1 || echo "chain_floor failed"
 python3 tools/kernel_bench.py > $out/kernel_bench.txt 2>&1
