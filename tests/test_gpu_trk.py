@@ -630,6 +630,54 @@ def test_vector_correlator_agrees_with_the_matrix_one(closed_loop, golden_defaul
     np.testing.assert_allclose(r[1]['dumps'], outs['dumps'], rtol=1e-3, atol=5e-5)
 
 
+def test_forced_delays_at_every_edge_agree_across_correlators(closed_loop, monkeypatch):
+    """The window boundary DELAY at every place the matrix correlator treats specially: all four
+    residues mod 4 (a K-step of four positions is issued in pieces around it), the edges of a
+    64-position tile, of a 512-position quarter and of the code period, 0 and 2047 -- forced
+    through replay on the recorded states.  (a) The batch form of the kernel (160 blocks in one
+    launch) and its single-block form (the same rows eight at a time) give the same bytes;
+    (b) the vector correlator (GPSMI_STREAM_MFMA=0: an independent kernel, float32 sums in
+    another order) agrees within the reference tolerance, integer fields exactly."""
+    from gpsmi.engine import TrkEngine, DeviceBuffer
+    eng, outs, states, blocks = closed_loop
+    nb0, nch = outs.shape
+    edges = [0, 1, 2, 3, 4, 5, 6, 7, 61, 62, 63, 64, 65, 66, 67, 127, 128, 129, 130, 131, 255, 256, 257,
+             509, 510, 511, 512, 513, 514, 515, 1021, 1022, 1023, 1024, 1025, 1026, 1027, 1535, 1536, 1537,
+             2040, 2041, 2042, 2043, 2044, 2045, 2046, 2047]
+    nb = 160
+    rows = np.arange(nb) % nb0
+    table = states[rows].copy()
+    rng = np.random.default_rng(11)
+    forced = np.empty((nb, nch), dtype=np.int32)
+    for i in range(nb):
+        for c in range(nch):
+            k = (i * nch + c)
+            if k % 3 == 0:        # near the true delay: the sums carry signal
+                forced[i, c] = (int(outs['delay_used'][rows[i], c]) + int(rng.integers(-5, 6))) % 2048
+            else:
+                forced[i, c] = edges[(k // 3 + 7 * c) % len(edges)]
+    buf = DeviceBuffer(nb * blocks[0].nbytes)
+    for i in range(nb):
+        buf.upload(blocks[rows[i]], i * blocks[0].nbytes)
+    whole = eng.replay(buf.ptr, nb, table, forced)
+    pieces = np.concatenate([eng.replay(buf.at(i * blocks[0].nbytes), 8, table[i:i + 8], forced[i:i + 8])
+                             for i in range(0, nb, 8)])
+    assert pieces.tobytes() == whole.tobytes()
+    assert np.array_equal(whole['delay_used'], forced)
+    monkeypatch.setenv('GPSMI_STREAM_MFMA', '0')
+    veng = TrkEngine(None, max_ch=nch)
+    monkeypatch.delenv('GPSMI_STREAM_MFMA')
+    for c in range(nch):
+        veng.open(c, int(states[0, c]['prn']), 0.0, 0)
+    vec = veng.replay(buf.ptr, nb, table, forced)
+    veng.close()
+    buf.free()
+    for k in ('mx', 'delay', 'delay_used', 'n_dumps', 'nps', 'first_len'):
+        assert np.array_equal(vec[k], whole[k]), k
+    np.testing.assert_allclose(vec['dumps'], whole['dumps'], rtol=1e-3, atol=5e-4)
+    np.testing.assert_allclose(vec['epl'], whole['epl'], rtol=1e-5)
+
+
 def test_time_domain_correlation_variant_agrees(closed_loop_hirate, golden_hirate, monkeypatch):
     """GPSMI_DIRECT_CORR=1: the exact time-domain correlation kernel (the fall-back for
     code periods beyond 16384 samples) against the same reference fixture as the
