@@ -560,8 +560,17 @@ def test_twenty_channels_four_groups():
         buf.upload(b, i * b.nbytes)
     rep = eng.replay(buf.ptr, len(blocks), states, outs['delay_used'])
     buf.free()
-    eng.close()
     assert rep.tobytes() == outs.tobytes()
+    # the same rows as one launch of 64 blocks: 128 (block, channel group) units = the BATCH form of
+    # the matrix correlator with two channel groups, the second one with eight of its twelve columns
+    rows = np.arange(64) % len(blocks)
+    big = DeviceBuffer(64 * blocks[0].nbytes)
+    for i in range(64):
+        big.upload(blocks[rows[i]], i * blocks[0].nbytes)
+    rep64 = eng.replay(big.ptr, 64, states[rows], outs['delay_used'][rows])
+    big.free()
+    eng.close()
+    assert rep64.tobytes() == outs[rows].tobytes()
     for c in (0, 7, 13, 19):                          # one channel of each group, alone
         solo = TrkEngine(max_ch=1)
         sv, f0, d0 = init[c]
