@@ -5,6 +5,8 @@
 //         tools/probe/span_prof.hip gps-sdr-receiver_amd/csrc/gpsmi_core.hip \
 //         gps-sdr-receiver_amd/csrc/gpsmi_acq.hip -o tools/probe/span_prof
 //   tools/probe/span_prof [blocks = 1024]
+// With -DGPSMI_SPAN_STAMPS (-o tools/probe/span_stamps): the checks, then the 100 MHz phase stamps of
+// one launch of the batch form (where a unit's time goes besides its tile loop) and nothing else.
 #include "../../gps-sdr-receiver_amd/csrc/gpsmi_trk.hip"
 
 #include <algorithm>
