@@ -162,7 +162,7 @@ __device__ __forceinline__ void pfa_dft_prime(fft_c* x, Pre pre, Out0 out0, Out 
 // every workgroup, into a buffer nothing else reads
 #ifdef GPSMI_PFA_STAMPS
 __device__ unsigned long long* g_pfa_stamps;
-#define PFA_STAMP(i) do { if (t == 0) g_pfa_stamps[(size_t)cell * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PFA_STAMP(i) do { if (t == 0) g_pfa_stamps[(size_t)cell * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define PFA_STAMP(i) do {} while (0)
 #endif
@@ -405,35 +405,49 @@ __global__ __launch_bounds__(kPfaThreads) void pfa_corr_kernel(
     }
     PFA_STAMP(5);
     request(cell + (MODE == 0 ? (int)gridDim.x : 1));
+    PFA_STAMP(8);
     sm = wave_sum_dpp(sm);
     s2 = wave_sum_dpp(s2);
     wave_argmax_dpp(bv, bi);
     if (lane == 0) { red_s[wave] = sm; red_d[wave] = s2; red_v[wave] = bv; red_i[wave] = bi; }
+    PFA_STAMP(9);
     lds_barrier();
-    if (t == 0) {
-        double dsm = 0.0, ds2 = 0.0;
-        bv = red_v[0]; bi = red_i[0];
-#pragma unroll
-        for (int w = 0; w < 16; ++w) { dsm += (double)red_s[w]; ds2 += (double)red_d[w]; }
-#pragma unroll
-        for (int w = 1; w < 16; ++w) {
-            const float ov = red_v[w];
-            const int oi = red_i[w];
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    PFA_STAMP(10);
+    // The sixteen partial results are combined by the first sixteen lanes of wave 0 together (the
+    // serial form on one thread -- 32 dependent double additions, two double divisions and a double
+    // square root -- was 4.2 K of a cell's 38 K cycles with fifteen waves waiting at the barrier
+    // behind it): a four-step DPP butterfly in double for the two sums, the wave argmax on the partial
+    // maxima, then mean and variance with the reciprocals of L as double constants and the square
+    // root in float (the rounding of the float results absorbs the difference).
+    if (wave == 0) {
+        const bool in = lane < 16;
+        double dsm = in ? (double)red_s[lane & 15] : 0.0, ds2 = in ? (double)red_d[lane & 15] : 0.0;
+        float pv = in ? red_v[lane & 15] : -1.f;
+        int pi = in ? red_i[lane & 15] : 0x7fffffff;
+        dsm = row_sum_f64_dpp(dsm);              // (lanes 0..15 are one DPP row)
+        ds2 = row_sum_f64_dpp(ds2);
+        wave_argmax_dpp(pv, pi);
+        if (lane < 2) {                          // lane 0: the neighbour below the peak, lane 1: the one above
+            const int nb = lane == 0 ? (pi > 0 ? pi - 1 : kPfaL - 1) : (pi < kPfaL - 1 ? pi + 1 : 0);
+            const float nv = data[(nb / kPfaC) * kPfaPitch + pfa_sigma(nb % kPfaC)].x;
+            const float hi = __shfl(nv, 1, 64);
+            if (lane == 0) {
+                const double inv_l = 1.0 / (double)kPfaL;
+                // population variance from the two sums (the squares were summed unscaled)
+                const double mean = dsm * inv_l;
+                const double var = ds2 * (inv_l * inv_l * inv_l) - mean * mean;
+                DirStats r;
+                r.argmax = pi;
+                r.peak = pv;
+                r.mean = (float)mean;
+                r.std = sqrtf((float)(var > 0.0 ? var : 0.0));
+                r.lo = nv;
+                r.hi = hi;
+                out[cell] = r;
+            }
         }
-        // population variance from the two sums (the squares were summed unscaled)
-        const double mean = dsm / (double)kPfaL;
-        const double var = ds2 / ((double)kPfaL * (double)kPfaL * (double)kPfaL) - mean * mean;
-        const int nlo = bi > 0 ? bi - 1 : kPfaL - 1, nhi = bi < kPfaL - 1 ? bi + 1 : 0;
-        DirStats r;
-        r.argmax = bi;
-        r.peak = bv;
-        r.mean = (float)mean;
-        r.std = (float)sqrt(var > 0.0 ? var : 0.0);
-        r.lo = data[(nlo / kPfaC) * kPfaPitch + pfa_sigma(nlo % kPfaC)].x;
-        r.hi = data[(nhi / kPfaC) * kPfaPitch + pfa_sigma(nhi % kPfaC)].x;
-        out[cell] = r;
     }
+    PFA_STAMP(11);
     lds_barrier();                              // (the neighbours are read: the next cell may write `data`)
     PFA_STAMP(6);
     cell += MODE == 0 ? (int)gridDim.x : 1;

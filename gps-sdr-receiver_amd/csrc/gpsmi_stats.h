@@ -27,6 +27,24 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// v + partner for a double, the partner's halves fetched by two DPP moves
+template <int CTRL>
+__device__ __forceinline__ double dpp_add_f64(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, false);
+    return v + __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+// sum over the 16 lanes of a DPP row, in every lane of the row (the adds commute: the partners of a
+// step hold the same bits)
+__device__ __forceinline__ double row_sum_f64_dpp(double v) {
+    v = dpp_add_f64<0xB1>(v);          // quad_perm [1,0,3,2]
+    v = dpp_add_f64<0x4E>(v);          // quad_perm [2,3,0,1]
+    v = dpp_add_f64<0x141>(v);         // row_half_mirror
+    v = dpp_add_f64<0x140>(v);         // row_mirror
+    return v;
+}
+
 template <int CTRL, int ROWS>
 __device__ __forceinline__ float dpp_max_own(float v) {   // max(v, partner), v where no partner
     const int vi = __builtin_bit_cast(int, v);

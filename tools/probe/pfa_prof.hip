@@ -1,7 +1,8 @@
 // Times pfa_corr_kernel (gpsmi_pfa.h: the 16368-point code-phase correlation of BASELINE
 // configs[4]) on random data, checks one cell against a float64 time-domain correlation on the
 // host, and prints where a workgroup spends its cycles (shader-clock stamps at the phase
-// boundaries: probe build only, -DGPSMI_PFA_STAMPS).  Tuning aid, not part of the library.
+// boundaries, and inside the statistics phase: probe build only, -DGPSMI_PFA_STAMPS).  Tuning aid,
+// not part of the library.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DGPSMI_PFA_STAMPS -Iinclude \
 //         -Igps-sdr-receiver_amd/csrc tools/probe/pfa_prof.hip -o tools/probe/pfa_prof
 //   tools/probe/pfa_prof [cells = 6144]
@@ -37,7 +38,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&d_xs, ncell * sizeof(int)));
     CK(hipMalloc(&d_rs, ncell * sizeof(int)));
     CK(hipMalloc(&d_st, ncell * sizeof(DirStats)));
-    CK(hipMalloc(&d_stamp, (size_t)ncell * 8 * sizeof(unsigned long long)));
+    CK(hipMalloc(&d_stamp, (size_t)ncell * 16 * sizeof(unsigned long long)));
     CK(hipMemcpy(d_x, x.data(), x.size() * sizeof(float2), hipMemcpyHostToDevice));
     CK(hipMemcpy(d_rep, rep.data(), rep.size() * sizeof(float), hipMemcpyHostToDevice));
     CK(hipMemcpy(d_xs, xsel.data(), ncell * sizeof(int), hipMemcpyHostToDevice));
@@ -87,17 +88,26 @@ int main(int argc, char** argv) {
         printf("%s\n", ok ? "check ok" : "CHECK FAILED");
     }
     // ---- phase stamps of the last launch: median over workgroups
-    std::vector<unsigned long long> sp((size_t)ncell * 8);
+    std::vector<unsigned long long> sp((size_t)ncell * 16);
     CK(hipMemcpy(sp.data(), d_stamp, sp.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     const char* names[6] = {"P1 load + FFT-16", "P2 3 x 11", "P3 31, x R, 31", "P4 3 x 11", "P5 FFT-16 + |.|", "statistics"};
     double tot = 0;
     for (int ph = 0; ph < 6; ++ph) {
         std::vector<double> d(ncell);
-        for (int c = 0; c < ncell; ++c) d[c] = (double)(sp[(size_t)c * 8 + ph + 1] - sp[(size_t)c * 8 + ph]);
+        for (int c = 0; c < ncell; ++c) d[c] = (double)(sp[(size_t)c * 16 + ph + 1] - sp[(size_t)c * 16 + ph]);
         std::nth_element(d.begin(), d.begin() + ncell / 2, d.end());
         printf("  %-18s %8.0f cycles (median over workgroups)\n", names[ph], d[ncell / 2]);
         tot += d[ncell / 2];
     }
     printf("  %-18s %8.0f cycles\n", "sum", tot);
+    // inside the statistics: request issued | wave reductions + LDS | first barrier | thread 0's part | second barrier
+    const int sub[6] = {5, 8, 9, 10, 11, 6};
+    const char* sn[5] = {"  request", "  wave reductions", "  first barrier", "  thread 0", "  second barrier"};
+    for (int k = 0; k < 5; ++k) {
+        std::vector<double> d(ncell);
+        for (int c = 0; c < ncell; ++c) d[c] = (double)(sp[(size_t)c * 16 + sub[k + 1]] - sp[(size_t)c * 16 + sub[k]]);
+        std::nth_element(d.begin(), d.begin() + ncell / 2, d.end());
+        printf("  %-18s %8.0f cycles\n", sn[k], d[ncell / 2]);
+    }
     return 0;
 }
