@@ -412,9 +412,10 @@ struct gpsmi_trk {
     int n_streams = 1;                   // independent receivers (IQ streams) of the closed loop; a state
                                          // row is stream * max_ch + channel
     int rows() const { return n_streams * max_ch; }
-    int span_single_max = 96;            // (block, channel group) units up to which the span correlator runs
-                                         // its single-block form (GPSMI_SPAN_SINGLE_MAX; measured: 51 against 56 us
-                                         // per step at 64 units, 79 against 67 at 128)
+    int span_single_max = 80;            // (block, channel group) units up to which the span correlator runs
+                                         // its single-block form (GPSMI_SPAN_SINGLE_MAX; measured per step with
+                                         // the round's final kernels: 50 against 56 us at 64 units, 69 against 63
+                                         // at 96, 81 against 66 at 128)
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;   // result read-back, overlaps the next replay run
     hipStream_t epi_stream = nullptr;    // replay: the epilogue of run k beside the code-phase
@@ -1240,10 +1241,14 @@ int gpsmi_trk_replay_run_async(gpsmi_trk* h, const void* d_iq, int nb) {
     h->cur ^= 1;                           // the other slot may still be on its way to the host
     gpsmi_trk::Slot& sl = h->slot[h->cur];
     if (sl.copy_pending) {                 // its previous results must have left first
+        // (that copy was queued behind the slot's epilogue -- replay_fetch_async -- so it stands for
+        // both: one barrier packet between this run's first kernel and the previous run's last
+        // instead of two, ~2 us of every step)
         GPSMI_HIP(hipStreamWaitEvent(h->stream, sl.copied, 0));
         sl.copy_pending = false;
+        sl.epi_pending = false;
     }
-    if (sl.epi_pending) {                  // ... and the epilogue that read its buffers be done
+    if (sl.epi_pending) {                  // ... or the epilogue that read its buffers be done
         GPSMI_HIP(hipStreamWaitEvent(h->stream, sl.epi_done, 0));
         sl.epi_pending = false;
     }
