@@ -490,25 +490,24 @@ __device__ __forceinline__ void span_wave(const void* __restrict__ blk, const vo
                     else kstep(o[s & 1], c1, c2, c3, std::false_type{});
                 }
             } else {
-                // (rolled: one copy of the checked path per half tile; the operands of the next two
-                // K-steps are on their way while these two are summed)
-                o[1] = read_ops(8 * hw + 1);
+                // (a boundary somewhere in this half tile: the same pipeline, every K-step asking
+                // whether it is the one; rolled over the two groups of four K-steps -- eight inlined
+                // copies of the checked path cost registers the combine step then reloads from
+                // scratch, behind the prefetched rows)
 #pragma unroll 1
-                for (int s = 0; s < 8; s += 2) {
-                    const int sn = s + 2 < 8 ? s + 2 : s;                 // (last: a harmless re-read)
-                    const Ops n0 = read_ops(8 * hw + sn), n1 = read_ops(8 * hw + sn + 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    sums(o[0]); sums(o[1]);
-                    const sp4 v = (s & 4) ? cd[2 * hw + 1] : cd[2 * hw];    // (selects, not indexed registers)
-                    sp_b3((s & 2) ? sp2{v.z, v.w} : sp2{v.x, v.y}, nk, u1, d1, u2, d2, u3, d3, b1, b2, b3);
-                    if (nb >= tpos + 4 * (8 * hw + s + 2)) {
-                        kstep(o[0], b1.x, b2.x, b3.x, std::false_type{});
-                        kstep(o[1], b1.y, b2.y, b3.y, std::false_type{});
-                    } else {
-                        kstep_checked(o[0], 8 * hw + s, b1.x, b2.x, b3.x);
-                        kstep_checked(o[1], 8 * hw + s + 1, b1.y, b2.y, b3.y);
+                for (int g = 0; g < 2; ++g) {
+                    const sp4 v = g ? cd[2 * hw + 1] : cd[2 * hw];          // (a select, not indexed registers)
+                    const int s0 = 8 * hw + 4 * g;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (j + 1 < 4 || g == 0) o[(j + 1) & 1] = read_ops(s0 + j + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        sums(o[j & 1]);
+                        if (!(j & 1)) sp_b3(j == 0 ? sp2{v.x, v.y} : sp2{v.z, v.w}, nk, u1, d1, u2, d2, u3, d3, b1, b2, b3);
+                        const float c1 = (j & 1) ? b1.y : b1.x, c2 = (j & 1) ? b2.y : b2.x, c3 = (j & 1) ? b3.y : b3.x;
+                        if (nb >= tpos + 4 * (s0 + j + 1)) kstep(o[j & 1], c1, c2, c3, std::false_type{});
+                        else kstep_checked(o[j & 1], s0 + j, c1, c2, c3);
                     }
-                    o[0] = n0; o[1] = n1;
                 }
             }
         };
