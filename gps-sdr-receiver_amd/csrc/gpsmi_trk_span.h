@@ -426,25 +426,9 @@ __device__ __forceinline__ void span_wave(const void* __restrict__ blk, const vo
     // one are behind us: LDS serves a wave in order) while tile t + 1 is requested (unconditional:
     // behind the last tile of the range it is the first one of the wave's next range, or a
     // position past the block, which costs no memory traffic)
-#ifdef GPSMI_SPAN_TOUCH
-    // experiment: touch the 128 cache lines of the tile after the one being requested (one dword per
-    // line: 16 KiB more on their way from HBM into L2 per wave for two load instructions)
-    float pf0 = 0.f, pf1 = 0.f;
-    const __amdgpu_buffer_rsrc_t touch_rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(blk), 0, CS * 32 * (int)sizeof(float2), kMfRsrcFlags);
-    const int touch_off = ((lane >> 2) * CS * (int)sizeof(float2)) + (lane & 3) * 128;
-#endif
     auto enter_tile = [&](int t) {
         load_half(2 * t + 1, cd[2], cd[3]);
         if (t + 1 < kTiles) load_half(2 * t + 2, cdn[0], cdn[1]);    // (the next RANGE fetches its own)
-#ifdef GPSMI_SPAN_TOUCH
-        if (FMT == 0 && t + 2 < kTiles) {
-            const int tb2 = (pos0 + (t + 2) * kSpTile) * (int)sizeof(float2);
-            const int tb3 = tb2 + 16 * CS * (int)sizeof(float2);
-            asm volatile("buffer_load_dword %0, %2, %3, %4 offen\n\tbuffer_load_dword %1, %2, %3, %5 offen"
-                         : "+v"(pf0), "+v"(pf1) : "v"(touch_off), "s"(touch_rs), "s"(tb2), "s"(tb3));
-        }
-#endif
         if (!(DIAG & 2)) {
             const bool more = t + 1 < kTiles;              // else: the first tile of the wave's next range
             sp_swap_tile<(DIAG & 8) ? 0 : 2, FMT>(tl, lane, st, more ? blk : next_blk,
@@ -538,9 +522,6 @@ __device__ __forceinline__ void span_wave(const void* __restrict__ blk, const vo
         cd[0] = cdn[0]; cd[1] = cdn[1];
         if (tix + 1 < kTiles) enter_tile(tix + 1);
     }
-#ifdef GPSMI_SPAN_TOUCH
-    asm volatile("" : "+v"(pf0), "+v"(pf1));          // (the touched dwords land here until the range is over)
-#endif
 }
 
 // probe builds only (tools/probe/span_prof.hip): the 100 MHz clock at the phase boundaries of every
