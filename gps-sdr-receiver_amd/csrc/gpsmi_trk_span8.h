@@ -13,8 +13,8 @@
 //       A[(r, im)][(pi, re)] =  x_im,   A[(r, im)][(pi, im)] =  x_re,      x = x[r][2 q + pi],
 //       B[(pi, kappa)][c]    =  component kappa of  replica_c[(m - d_c) mod CS] exp(-j theta_c(m)).
 //   One MFMA per pair of positions does the 8 x 12 complex multiply-accumulates of both: the same
-//   two matrix-pipe cycles per row and position as the 32-row kernel (which needs four MFMAs per
-//   pair), every row of M in use.  (The vector kernel this replaces rebuilt B for every group of
+//   two matrix-pipe cycles per row and position as the four-product form of the 32-row kernel had
+//   (its three-product form needs M = rows alone: not with eight rows), every row of M in use.  (The vector kernel this replaces rebuilt B for every group of
 //   six channels and amortised it over 8 rows instead of 32: 0.29 ms per 512 MiB, 23 % of the HBM
 //   peak, bound by VALU issue.)
 //   A lane holds ONE real number of B per pair -- component kappa at parity pi for its channel --
