@@ -157,8 +157,9 @@ def test_replay_without_forced_delay(closed_loop):
 
 def test_raw_u8_input_equals_complex64_input(closed_loop, golden_default):
     """Fused ingest (gpsrecv.py:162-173): the kernels that read IQ decode the recorder's
-    uint16 (Q << 8 | I) samples themselves.  Closed loop (host blocks, single-block kernels)
-    and replay (batch kernels) on the raw blocks must equal the complex64 path byte for byte."""
+    uint16 (Q << 8 | I) samples themselves.  Closed loop (host blocks), replay of the recorded rows
+    (single-block form of the correlator) and replay of 96 blocks in one launch (its batch form) on
+    the raw blocks must equal the complex64 path byte for byte."""
     from conftest import scene_for
     from gpsmi.engine import TrkEngine, DeviceBuffer
     _, outs, states, _ = closed_loop
@@ -176,8 +177,17 @@ def test_raw_u8_input_equals_complex64_input(closed_loop, golden_default):
         buf.upload(b, i * b.nbytes)
     rep = eng.replay(buf.ptr, nb, states, outs['delay_used'])
     buf.free()
-    eng.close()
     assert rep.tobytes() == outs.tobytes()
+    # the same rows tiled to 96 blocks in one launch: past the point where the matrix correlator
+    # switches from its single-block form to its batch form (the raw-sample variant of that one)
+    rows = np.arange(96) % nb
+    big = DeviceBuffer(96 * raw[0].nbytes)
+    for i in range(96):
+        big.upload(raw[rows[i]], i * raw[0].nbytes)
+    rep96 = eng.replay(big.ptr, 96, states[rows], outs['delay_used'][rows])
+    big.free()
+    eng.close()
+    assert rep96.tobytes() == outs[rows].tobytes()
     # other block / code lengths have no fused path: refused, not silently converted
     from gpsmi.engine import Config, EngineError
     e2 = TrkEngine(Config(code_samples=16368, n_cyc=8), max_ch=2)
