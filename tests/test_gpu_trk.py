@@ -761,7 +761,7 @@ def test_result_slots_carry_nothing_over(closed_loop):
     assert (again['prn'][:, 0] > 0).all()
 
 
-@pytest.mark.parametrize('R', [1, 8, 32])
+@pytest.mark.parametrize('R', [1, 8, 32, 96])        # (96: past the correlator's switch to its batch form)
 def test_batched_receivers_equal_their_solo_closed_loops(golden_default, R):
     """gpsmi_trk_set_streams: R independent IQ streams tracked by one handle, all channels of
     all streams in every launch trio.  Stream r must produce, byte for byte, the records and
