@@ -110,3 +110,15 @@ def geometric_scene(truth, seconds, tow0=50001, lead_s=0.25, n_sats=8, amp=0.11,
                         n_cyc=n_cyc)
     return scene, {'ephs': ephs, 'truth': truth, 'tow0': tow0, 't0_gps': t0_gps,
                    'fit_err_samples': fit_err}
+
+
+HANDOFF_SECONDS = 14.0
+
+
+def handoff_scene():
+    """(scene, info, n_blocks) of the hand-off fixture (tests/golden/ref_handoff.npz: what the
+    reference's own gpsrecv.main() sent for this recording): 14 s, eight satellites with real
+    subframes, at the README's position."""
+    truth = np.array(position.geo_to_ecef(49.082961, 8.307581, 160.0))
+    scene, info = geometric_scene(truth, HANDOFF_SECONDS, seed=79)
+    return scene, info, int(HANDOFF_SECONDS / 0.032)

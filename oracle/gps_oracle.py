@@ -642,3 +642,63 @@ class SatStream:
                 self.freq = self.confine(self.freq + df)
                 self.last.update(df=df, shift=shift)
         return self.sweep, frames, code_phase, (self.corr_q, self.corr_l)
+
+
+# --------------------------------------------------------------------------
+# the block loop and the hand-off (gpsrecv.py:370-417, :445-519)
+# --------------------------------------------------------------------------
+def process_data(blocks, p=None, sat_all=None):
+    """processData's data path (gpsrecv.py:466-519) over an iterable of complex64 blocks,
+    with the pool bookkeeping of delPoolStreams / initPoolStreams / satCalc (:370-417) kept
+    as the reference has it (worker slots filled in slot order from ``newSatSet.pop()``,
+    results in the iteration order of ``actSatSet``): yields ``(block_index, (skippedData,
+    frameLst, coPhLst))`` for every block on which the reference sends a datagram."""
+    p = p or Params()
+    t = sec_time(p)
+    sat_all = list(range(2, 33)) if sat_all is None else list(sat_all)   # gpsrecv.py:36
+    spectra = {s: fft_cacode(s, p.code_samples) for s in sat_all}
+    sat_lst, found, freq = sat_all.copy(), [], p.min_freq
+    sweeping, smp_time = True, np.int64(0)
+    pool_worker = [0] * p.max_sat                       # initMultiProcPool (:358)
+    streams = [None] * p.max_sat
+    act = set()
+    co_ph_lst, cp_q_lst, skipped = {}, {}, 0
+    for i, data in enumerate(blocks):
+        smp_time += p.ngps                              # :471 (no skips in file mode)
+        if sweeping:
+            ready, freq, found = sweep_all_sats(data, freq, sat_lst, found,
+                                                p.it_sweep_all, p, spectra, t)
+            if ready:
+                sweeping = False
+                dele, new = get_new_sats(act, found, cp_q_lst, p.max_sat)
+                for s in dele:                          # delPoolStreams (:370-382)
+                    w = pool_worker.index(s)
+                    streams[w] = None
+                    pool_worker[w] = 0
+                act = act - dele
+                if len(new) > 0:                        # initPoolStreams (:385-401)
+                    for w, sno in enumerate(pool_worker):
+                        if sno == 0:
+                            s = new.pop()
+                            pool_worker[w] = s
+                            _, _, f0, d0 = [e for e in found if e[1] == s][0]
+                            streams[w] = SatStream(s, f0, p, delay=d0)
+                            act.add(s)
+                            if len(new) == 0:
+                                break
+            continue
+        res_lst = []                                    # satCalc (:404-417)
+        for s in act:
+            ss = streams[pool_worker.index(s)]
+            sw, f_lst, co_ph, cp_q = ss.process(data, smp_time)
+            res_lst.append((sw, ss.sat_no, f_lst, co_ph, cp_q))
+        frame_lst = []
+        stream_no = smp_time // p.ngps
+        for sw, s, f_lst, co_ph, cp_q in res_lst:       # :496-505
+            frame_lst += f_lst
+            cp_q_lst[s] = cp_q
+            if co_ph >= 0:
+                co_ph_lst.setdefault(s, []).append((stream_no, co_ph))
+        if len(frame_lst) > 0:                          # :509-519
+            yield i, (skipped, frame_lst, co_ph_lst)
+            co_ph_lst, skipped = {}, 0

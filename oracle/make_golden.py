@@ -16,6 +16,7 @@ detected.
     python oracle/make_golden.py navbits    # Subframe / evalGpsBits on constructed frames
     python oracle/make_golden.py position   # SatOrbit / SatPos / leastSquaresPos4 / ecefToGeo
     python oracle/make_golden.py resweep    # SatStream.initSweep / sweepFrequency / restoreFreq
+    python oracle/make_golden.py handoff    # gpsrecv.main(): file -> streamData -> processData -> datagrams
 
 The reference binds its configuration at import time (``from gpsglob import``),
 so each configuration runs in its own interpreter.
@@ -538,6 +539,78 @@ def run_newsats():
     print(path, os.path.getsize(path), 'bytes', sum(len(c['new']) for c in cases), 'new in all')
 
 
+def handoff_scene():
+    """The hand-off fixture scene; tests rebuild it with gpsmi.synth_nav.handoff_scene()."""
+    from gpsmi import synth_nav
+    return synth_nav.handoff_scene()
+
+
+def run_handoff():
+    """The receiver process of the reference itself, end to end, on a recording
+    (gpsrecv.py:553-579): the scene is written as the recorder's u8 .bin file, gpsglob's
+    file-mode settings point at it (LIVE_MEAS = False is the default, BIN_DATA / DATA_PATH),
+    SAVE_PICKLE = True, and the real ``main()`` runs -- streamData (:153-186) reading and
+    decoding the file, processData (:445-548) with the spawn worker pool (initMultiProcPool,
+    initPoolStreams, satCalc, :340-417), sweepAllSats, getNewSats, the hand-off
+    ``pickle.dumps((skippedData, frameLst, coPhLst))`` and saveResults (:205-212).  The
+    pickle file that run writes (our own run's output) is unpickled here and frozen as
+    JSON in ref_handoff.npz: every datagram with every key in order, value and type name.
+    SEND_OVER_UDP is switched off (gpsglob.py:25 allows that with SAVE_PICKLE)."""
+    import asyncio
+    import json
+    import multiprocessing as mp
+    import pickle
+    import shutil
+    import numpy as np
+    gpsglob, gpslib, gpsrecv = _import_reference(2048, 32)
+    scene, info, n_blocks = handoff_scene()
+    tmp = tempfile.mkdtemp(prefix='gps_handoff_')
+    h = hashlib.sha256()
+    with open(os.path.join(tmp, 'handoff.bin'), 'wb') as f:
+        for b in range(n_blocks):
+            raw = scene.block_raw(b)
+            h.update(raw.tobytes())
+            raw.astype('<u2').tofile(f)
+    # the spawned workers re-import gpsrecv: they need the same module path
+    os.environ['PYTHONPATH'] = os.pathsep.join(sys.path[:3] + [os.environ.get('PYTHONPATH', '')])
+    os.environ['PYTHONDONTWRITEBYTECODE'] = '1'
+    gpsrecv.FFT_CACODE = [0, 0] + gpsrecv.FFT_CACODE[2:]       # as __main__ builds it (:574-577)
+    gpsrecv.DATA_PATH = tmp + os.sep
+    gpsrecv.BIN_DATA = 'handoff.bin'
+    gpsrecv.SAVE_PICKLE = True
+    gpsrecv.SEND_OVER_UDP = False
+    gpsrecv.SAVE_DATE = 'handoff'
+    assert gpsrecv.LIVE_MEAS is False and gpsrecv.START_STREAM == 0
+    mp.set_start_method('spawn')                               # gpsrecv.py:572
+    asyncio.run(gpsrecv.main())
+    with open(os.path.join(tmp, 'handoff_gpsResult.pickle'), 'rb') as f:
+        result_list = pickle.load(f)                           # written by the run above
+    shutil.rmtree(tmp)
+
+    def enc(v):
+        if isinstance(v, (bool, np.bool_)):
+            return [type(v).__name__, bool(v)]
+        if isinstance(v, (int, np.integer)):
+            return [type(v).__name__, int(v)]
+        if isinstance(v, (float, np.floating)):
+            return [type(v).__name__, float(v)]                # (float32 -> double: exact)
+        raise TypeError(type(v))
+    dgs = []
+    for res in result_list:
+        skipped, frame_lst, co_ph = pickle.loads(res)
+        dgs.append({'skipped': enc(skipped),
+                    'frames': [[[k, enc(v)] for k, v in d.items()] for d in frame_lst],
+                    'coph': [[int(s), [[enc(n), enc(c)] for n, c in lst]]
+                             for s, lst in co_ph.items()]})
+    path = os.path.join(GOLD, 'ref_handoff.npz')
+    np.savez_compressed(path, numpy=np.__version__, n_blocks=n_blocks,
+                        iq_sha256=h.hexdigest(), datagrams=np.array(json.dumps(dgs)))
+    n_sub = sum(1 for d in dgs for f in d['frames'] if any(k == 'ID' for k, _ in f))
+    print(path, os.path.getsize(path), 'bytes;', len(dgs), 'datagrams,', n_sub,
+          'decoded subframes, satellites',
+          sorted({v[1] for d in dgs for f in d['frames'] for k, v in f if k == 'SAT'}))
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1:
         if sys.argv[1] == 'newsats':
@@ -548,6 +621,8 @@ if __name__ == '__main__':
             run_position()
         elif sys.argv[1] == 'resweep':
             run_resweep()
+        elif sys.argv[1] == 'handoff':
+            run_handoff()
         else:
             run(sys.argv[1])
     else:
@@ -555,6 +630,7 @@ if __name__ == '__main__':
         subprocess.check_call([sys.executable, os.path.abspath(__file__), 'navbits'])
         subprocess.check_call([sys.executable, os.path.abspath(__file__), 'position'])
         subprocess.check_call([sys.executable, os.path.abspath(__file__), 'resweep'])
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), 'handoff'])
         for cfg in ('default', 'hirate'):
             subprocess.check_call([sys.executable, os.path.abspath(__file__),
                                    cfg])

@@ -1,7 +1,10 @@
 """GPU: the block loop + hand-off (gpsmi.pipeline.Receiver, mirror of
-gpsrecv.processData's data path, reference gpsrecv.py:445-548) against the same
-loop written with the oracle's functions: same datagrams at the same blocks,
-same structure after unpickling, numbers within the tracking tolerances."""
+gpsrecv.processData's data path, reference gpsrecv.py:445-548).  The datagrams of the
+reference's own process are tests/test_handoff.py (ref_handoff.npz, 8 satellites); here the
+12-satellite default scene (MAX_SAT = 11 of 12 selected) against oracle.process_data, which
+that fixture pins bit for bit: same datagrams at the same blocks, same structure after
+unpickling, numbers within the tracking tolerances.  Then the commands, skips, raw input and
+the streamed forms."""
 import pickle
 
 import numpy as np
@@ -14,46 +17,10 @@ pytestmark = pytest.mark.gpu
 N_BLOCKS = 45
 
 
-def oracle_process_data(blocks):
-    """processData's data path (gpsrecv.py:466-519) with oracle pieces."""
-    p = orc.Params()
-    t = orc.sec_time(p)
-    spectra = {s: orc.fft_cacode(s) for s in range(2, 33)}
-    sat_lst, found, freq = list(range(2, 33)), [], p.min_freq
-    sweeping, smp_time = True, np.int64(0)
-    streams, act = {}, set()
-    co_ph_lst, cp_q_lst, skipped, out = {}, {}, 0, []
-    for i, data in enumerate(blocks):
-        smp_time += p.ngps
-        if sweeping:
-            ready, freq, found = orc.sweep_all_sats(data, freq, sat_lst, found,
-                                                    p.it_sweep_all, p, spectra, t)
-            if ready:
-                sweeping = False
-                dele, new = orc.get_new_sats(act, found, cp_q_lst, p.max_sat)
-                for s in new:
-                    _, _, f0, d0 = [e for e in found if e[1] == s][0]
-                    streams[s] = orc.SatStream(s, f0, p, delay=d0)
-                    act.add(s)
-            continue
-        frame_lst = []
-        stream_no = smp_time // p.ngps
-        for s in act:
-            sw, f_lst, co_ph, cp_q = streams[s].process(data, smp_time)
-            frame_lst += f_lst
-            cp_q_lst[s] = cp_q
-            if co_ph >= 0:
-                co_ph_lst.setdefault(s, []).append((stream_no, co_ph))
-        if frame_lst:
-            out.append((i, (skipped, frame_lst, co_ph_lst)))
-            co_ph_lst, skipped = {}, 0
-    return out
-
-
 def test_block_loop_and_hand_off():
     from gpsmi.pipeline import Receiver
     blocks = scene_blocks('default', 0, N_BLOCKS)
-    ref = oracle_process_data(blocks)
+    ref = list(orc.process_data(blocks))      # (pinned to gpsrecv.main()'s own datagrams: test_handoff.py)
     rx = Receiver()
     got = []
     for i, b in enumerate(blocks):
