@@ -287,8 +287,8 @@ static int acq_build(const gpsmi_cfg* cfg, gpsmi_acq* h) {
     if (h->direct) {
         GPSMI_HIP(hipMalloc((void**)&h->d_rep_time,
                             (size_t)(GPSMI_MAX_PRN + 1) * cfg->code_samples * sizeof(float)));
-        const char* force = getenv("GPSMI_DIRECT_CORR");          // 1: keep the time-domain kernel,
-        const int forced = force ? atoi(force) : 0;               // 2: the zero-padded 32768-point pair
+        long long forced = 0;                    // option "codephase": 1 keeps the time-domain kernel,
+        default_opt("codephase", &forced, 0);    // 2 the zero-padded 32768-point pair
         h->pfa = cfg->code_samples == kPfaL && forced == 0;
         h->big = !h->pfa && 2 * cfg->code_samples - 1 <= kBigN && forced != 1;
         if (h->pfa) {

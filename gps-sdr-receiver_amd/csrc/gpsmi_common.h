@@ -27,6 +27,11 @@ int fail(int code, const char* fmt, ...);
         if (!(cond)) return ::gpsmi::fail(GPSMI_E_ARG, "%s: %s", __func__, msg); \
     } while (0)
 
+// Process-wide defaults of the options a handle takes at create time (gpsmi_set_default in gpsmi.h):
+// the value set through the ABI, else the environment variable of the same meaning, else `fallback`.
+// Keys: see the table in gpsmi_core.hip.  -> false for an unknown key.
+bool default_opt(const char* key, long long* value, long long fallback);
+
 // exp(-2 pi i k / 2048) computed in double, rounded once.
 void make_twiddles(std::vector<float2>& tw);
 

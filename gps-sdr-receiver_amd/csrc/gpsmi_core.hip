@@ -1,7 +1,9 @@
 // libgpsmi core: error text, device buffers, the u8-IQ unpack kernel.
 #include <cmath>
 #include <cstddef>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "gpsmi_common.h"
 
@@ -22,6 +24,47 @@ int fail(int code, const char* fmt, ...) {
     vsnprintf(last_error_buf(), 512, fmt, ap);
     va_end(ap);
     return code;
+}
+
+// The options of gpsmi_set_default / gpsmi_trk_set_option (include/gpsmi.h) and the environment
+// variable that sets each one's default when the ABI has not.
+struct OptDef { const char* key; const char* env; bool set; long long value; };
+static OptDef g_opts[] = {
+    {"correlator", "GPSMI_STREAM_MFMA", false, 0},
+    {"codephase", "GPSMI_DIRECT_CORR", false, 0},
+    {"corr_cg", "GPSMI_CORR_CG", false, 0},
+    {"corr_small1", nullptr, false, 0},
+    {"corr_small2", nullptr, false, 0},
+    {"span_single_max", "GPSMI_SPAN_SINGLE_MAX", false, 0},
+    {"stream_inline_max", "GPSMI_STREAM_INLINE_MAX", false, 0},
+    {"done_by_dispatch", "GPSMI_DONE_BY_DISPATCH", false, 0},
+    {"corr_overlap", "GPSMI_CORR_OVERLAP", false, 0},
+    {"debug_flags", "GPSMI_DEBUG_FLAGS", false, 0},
+};
+static std::mutex g_opts_mutex;
+
+static OptDef* find_opt(const char* key) {
+    if (!key) return nullptr;
+    for (auto& o : g_opts)
+        if (strcmp(o.key, key) == 0) return &o;
+    return nullptr;
+}
+
+bool default_opt(const char* key, long long* value, long long fallback) {
+    std::lock_guard<std::mutex> lock(g_opts_mutex);
+    OptDef* o = find_opt(key);
+    if (!o) return false;
+    *value = fallback;
+    if (o->set) {
+        *value = o->value;
+    } else if (strcmp(key, "corr_small1") == 0 || strcmp(key, "corr_small2") == 0) {
+        int a1 = 0, a2 = 0;                              // GPSMI_CORR_SMALL="a1,a2"
+        const char* e = getenv("GPSMI_CORR_SMALL");
+        if (e && sscanf(e, "%d,%d", &a1, &a2) == 2 && a1 >= 0 && a2 >= a1) *value = key[10] == '1' ? a1 : a2;
+    } else if (o->env) {
+        if (const char* e = getenv(o->env)) *value = atoll(e);
+    }
+    return true;
 }
 
 void make_twiddles(std::vector<float2>& tw) {
@@ -69,6 +112,23 @@ int gpsmi_abi_sizeof(int which) {
         case 4: return (int)offsetof(gpsmi_trk_out, code_phase);
         default: return -1;
     }
+}
+
+int gpsmi_set_default(const char* key, long long value) {
+    std::lock_guard<std::mutex> lock(g_opts_mutex);
+    OptDef* o = find_opt(key);
+    if (!o) return fail(GPSMI_E_ARG, "gpsmi_set_default: unknown option '%s'", key ? key : "(null)");
+    o->set = true;
+    o->value = value;
+    return GPSMI_OK;
+}
+
+int gpsmi_clear_default(const char* key) {
+    std::lock_guard<std::mutex> lock(g_opts_mutex);
+    OptDef* o = find_opt(key);
+    if (!o) return fail(GPSMI_E_ARG, "gpsmi_clear_default: unknown option '%s'", key ? key : "(null)");
+    o->set = false;
+    return GPSMI_OK;
 }
 
 int gpsmi_device_count(int* n) {

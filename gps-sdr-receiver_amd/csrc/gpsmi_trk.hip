@@ -120,7 +120,6 @@ __device__ inline double fit_code_phase(double lo, double pk, double hi, int mx)
 
 #pragma clang fp contract(fast)
 #include "gpsmi_trk_stream.h"
-#include "gpsmi_trk_stream_mfma.h"
 #include "gpsmi_trk_corr.h"
 #include "gpsmi_bigfft.h"
 #include "gpsmi_pfa.h"
@@ -180,6 +179,8 @@ __device__ __forceinline__ void epilogue_job(const gpsmi_trk_state& si, gpsmi_tr
     const int nps = si.nps, df_len = si.df_len, was_locked = si.phase_locked;
     const float freq0 = si.freq, phase0 = si.phase, omega0 = si.omega0;
     const float prev_r = si.prev_sum_re, prev_i = si.prev_sum_im;
+    const int edge_state0 = si.edge_state;
+    const float prev_signal0 = si.prev_signal, std_dev0 = si.std_dev;
     for (int i = lane; i < df_len; i += 64) s_df_w[i] = si.df[i];
 
     // ---- prompt dumps: windows of decodeData (gpslib.py:1403-1420, :1440)
@@ -204,6 +205,50 @@ __device__ __forceinline__ void epilogue_job(const gpsmi_trk_state& si, gpsmi_tr
     if (lane < GPSMI_MAX_DUMPS) {
         o.dumps[2 * lane] = lane < nd ? gr : 0.f;
         o.dumps[2 * lane + 1] = lane < nd ? gi : 0.f;
+    }
+
+    // ---- edge scan of decodeData (gpslib.py:1394-1398, :1421-1436): while PHASE_LOCKED (the flag
+    // before this block's PLL), a dump is an edge when its sign differs from prevSign, the dump
+    // before it carried prevSign's sign (prevSign * PREV_SIGNAL > 0) and the step between the two
+    // exceeds MIN_EDGE_AMP = 3 * STD_DEV (of the block before).  prevSign only changes at an edge,
+    // so the scan jumps from edge to edge over three wave-wide bit masks (scalar arithmetic, the
+    // same in every lane): P / N = dump positive / negative, B = step large enough.
+    unsigned long long edge_mask = 0;
+    int edge_sign0 = 0, edge_state = edge_state0, ms_count = 0;
+    float prev_signal = prev_signal0;
+    if (was_locked) {
+        const unsigned long long V = (1ull << nd) - 1;             // nd <= 33
+        const float thr = mul_rn(3.0f, std_dev0);
+        const float re_up = __shfl_up(gr, 1, 64);
+        const float re_prev = lane == 0 ? prev_signal0 : re_up;
+        const unsigned long long Pm = __ballot(gr > 0.f) & V, Nm = __ballot(gr < 0.f) & V;
+        const unsigned long long Bm = __ballot(fabsf(sub_rn(gr, re_prev)) > thr) & V;
+        const unsigned long long Pp = (Pm << 1) | (prev_signal0 > 0.f ? 1ull : 0ull);   // the dump before
+        const unsigned long long Np = (Nm << 1) | (prev_signal0 < 0.f ? 1ull : 0ull);
+        unsigned long long todo = V;
+        int p = edge_state0 == 2 ? 0 : edge_state0;
+        if (edge_state0 == 0) {            // EDGES[0] == 0: every dump stores its sign until one is non-zero
+            const unsigned long long nz = Pm | Nm;
+            if (nz == 0) {
+                todo = 0;
+            } else {
+                const int j = __builtin_ctzll(nz);
+                p = ((Pm >> j) & 1) ? 1 : -1;
+                edge_sign0 = p;
+                todo = V & ~((2ull << j) - 1);
+            }
+        }
+        while (p != 0 && todo != 0) {
+            const unsigned long long cand = (p > 0 ? (Pp & ~Pm) : (Np & ~Nm)) & Bm & todo;
+            if (cand == 0) break;
+            const int i = __builtin_ctzll(cand);
+            edge_mask |= 1ull << i;
+            p = ((Pm >> i) & 1) ? 1 : (((Nm >> i) & 1) ? -1 : 0);
+            todo &= ~((2ull << i) - 1);
+        }
+        if (edge_state0 != 0 || edge_sign0 != 0) edge_state = p == 0 ? 2 : p;
+        prev_signal = __shfl(gr, nd - 1, 64);                      // PREV_SIGNAL = m.real of the last dump
+        ms_count = nd;
     }
 
     // ---- amplitude statistics (gpslib.py:1186-1187), float32 like numpy
@@ -277,6 +322,10 @@ __device__ __forceinline__ void epilogue_job(const gpsmi_trk_state& si, gpsmi_tr
         so.prev_sum_im = car_i;
         so.df_len = new_len;
         so.omega0 = om_new;
+        so.edge_state = edge_state;
+        so.prev_signal = prev_signal;
+        so.std_dev = sdev;
+        so.reserved = 0;
         o.n_dumps = nd;
         o.first_len = (n1 == 0) ? cs : n1;
         o.std_dev = sdev;
@@ -287,7 +336,10 @@ __device__ __forceinline__ void epilogue_job(const gpsmi_trk_state& si, gpsmi_tr
         o.phase = phase;
         o.phase_locked = locked;
         o.nps = nps_new;
-        o.reserved1 = 0;
+        o.edge_mask = (uint32_t)edge_mask;
+        o.edge_mask_hi = (uint32_t)(edge_mask >> 32);
+        o.edge_sign0 = edge_sign0;
+        o.ms_count = ms_count;
     }
 }
 
@@ -469,14 +521,14 @@ struct gpsmi_trk {
     bool replay_forced = false;
     int corr_cg = 4;
     int corr_small1 = 384, corr_small2 = 1536;   // jobs per launch up to which 1 / 2 channels per correlation workgroup
-    int done_by_dispatch = 1;          // GPSMI_DONE_BY_DISPATCH=0: an event record behind the correlator instead
+    int done_by_dispatch = 1;          // option "done_by_dispatch" = 0: an event record behind the correlator instead
     // code_samples != 2048: time-domain correlation + chunked correlator
     bool general = false;
     static constexpr int stream_j = 8;   // code positions per lane of the vector correlator
-    int mfma = 0;                    // MFMA correlator (default where it applies): 4 = span form
-                                     // (gpsmi_trk_span.h); 3 = the round-1 32x32x2 form, four waves per
-                                     // workgroup, three workgroups per CU
-    float* d_code2 = nullptr;        // [GPSMI_MAX_PRN + 1][2 cs]: replica twice (no index wrap)
+    int mfma = 0;                    // 4: the span form of the matrix-pipe correlator (gpsmi_trk_span.h),
+                                     // the default where it applies; 0: another correlator
+    int codephase = 0;               // option "codephase" as taken at create time
+    int corr_overlap = 0;            // option "corr_overlap": see gpsmi_trk_replay_run_async
     float* d_code_eo = nullptr;      // [GPSMI_MAX_PRN + 1][...]: the replica re-cut for the matrix correlators.  Span form
                                      // (2048): four planes by index mod 4, entry h of plane e = replica[(4 h + e) mod 2048],
                                      // 1024 entries each (a lane's run never wraps); span8 form: two planes by index
@@ -588,7 +640,7 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
         const int jobs_all = nblocks * nch;
         const int cg = jobs_all <= h->corr_small1 ? 1 : (jobs_all <= h->corr_small2 ? 2 : h->corr_cg);
         const int ng = (nch + cg - 1) / cg;
-        const dim3 cgrid(nblocks < 8 ? nblocks * ng : ((nblocks + 7) / 8) * 8 * ng);
+        const dim3 cgrid(corr_grid(nblocks, ng));
 #define GPSMI_LAUNCH_CORR(CGV)                                                                          \
     do {                                                                                              \
         if (u8)                                                                                       \
@@ -617,8 +669,7 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
     const dim3 span_grid((span_units + span_per - 1) / (span_per > 0 ? span_per : 1));
     if (timed && !ext_timed) GPSMI_HIP(hipEventRecord(sl.ev[1], h->stream));
     if (h->mfma) {                         // the correlator on the matrix pipe
-        const int ng12 = (nch + kMfCh - 1) / kMfCh;
-        const dim3 mgrid(((nblocks + 7) / 8) * 8 * ng12);
+        const int ng12 = (nch + kSpCh - 1) / kSpCh;
         if (h->mfma == 4 && span_single && u8)
             hipLaunchKernelGGL((trk_span_kernel<1, 1, 1>), dim3(nblocks * ng12 * 32), dim3(64), 0, h->stream,
                                d_iq_v, sl.d_mid, h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
@@ -649,12 +700,9 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
         } else if (h->mfma == 4 && u8)
             hipLaunchKernelGGL((trk_span_kernel<8, 4, 1>), span_grid, dim3(256), 0, h->stream,
                                d_iq_v, sl.d_mid, h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
-        else if (h->mfma == 4)
+        else
             hipLaunchKernelGGL((trk_span_kernel<8, 4, 0>), span_grid, dim3(256), 0, h->stream,
                                d_iq_v, sl.d_mid, h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
-        else
-            hipLaunchKernelGGL(trk_stream_mfma_kernel<4>, mgrid, dim3(256), 0, h->stream, d_iq,
-                               sl.d_mid, h->d_code2, P, ng12, nblocks, sl.d_partial);
     } else if (h->span8) {                 // CS = 16368, N_CYC = 8 on the matrix pipe
         const int ng12 = (nch + kSpCh - 1) / kSpCh;
         const int nwaves = nblocks * ng12 * kS8Ranges;
@@ -822,24 +870,22 @@ static int trk_build(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk* h) {
     const size_t code_bytes = (size_t)(GPSMI_MAX_PRN + 1) * cfg->code_samples * sizeof(float);
     GPSMI_HIP(hipMalloc((void**)&h->d_code, code_bytes));
     GPSMI_HIP(hipMemset(h->d_code, 0, code_bytes));          // slot 0: closed channels
+    long long want_matrix = 1;           // option "correlator": 0 keeps the vector kernel (gpsmi_trk_stream.h)
+    default_opt("correlator", &want_matrix, 1);
     {
-        const char* mf = getenv("GPSMI_STREAM_MFMA");
-        // default for CS = 2048, N_CYC = 32: the span form of the MFMA correlator;
-        // GPSMI_STREAM_MFMA=3 selects the 32x32x2 form (round 1), =0 the vector kernel.  One form per handle: the closed loop and the
-        // replay of a handle sum in the same order (bytewise equal results).
-        h->mfma = (!h->general && cfg->n_cyc == 32 && !(mf && atoi(mf) == 0)) ? (mf && atoi(mf) == 3 ? 3 : 4) : 0;
+        // default for CS = 2048, N_CYC = 32: the span form of the MFMA correlator.  One form per handle:
+        // the closed loop and the replay of a handle sum in the same order (bytewise equal results).
+        h->mfma = (!h->general && cfg->n_cyc == 32 && want_matrix != 0) ? 4 : 0;
         if (h->mfma) {
             const size_t b2 = (size_t)(GPSMI_MAX_PRN + 1) * 2 * kFftN * sizeof(float);
-            GPSMI_HIP(hipMalloc((void**)&h->d_code2, b2));
-            GPSMI_HIP(hipMemset(h->d_code2, 0, b2));
             GPSMI_HIP(hipMalloc((void**)&h->d_code_eo, b2));
             GPSMI_HIP(hipMemset(h->d_code_eo, 0, b2));
-
         }
     }
     if (h->general) {
-        const char* force = getenv("GPSMI_DIRECT_CORR");     // 1: keep the time-domain kernel,
-        const int forced = force ? atoi(force) : 0;          // 2: the zero-padded 32768-point pair
+        long long forced = 0;                    // option "codephase": 1 keeps the time-domain kernel,
+        default_opt("codephase", &forced, 0);    // 2 the zero-padded 32768-point pair
+        h->codephase = (int)forced;
         h->pfa = cfg->code_samples == kPfaL && forced == 0;
         h->big = !h->pfa && 2 * cfg->code_samples - 1 <= kBigN && forced != 1;
     }
@@ -849,8 +895,7 @@ static int trk_build(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk* h) {
         GPSMI_HIP(hipMemset(h->d_RSp, 0, b));                // slot 0: closed channels
     }
     {
-        const char* mf = getenv("GPSMI_STREAM_MFMA");        // =0 keeps the vector correlator
-        h->span8 = h->general && cfg->code_samples == kS8Cs && cfg->n_cyc == kS8Rows && !(mf && atoi(mf) == 0);
+        h->span8 = h->general && cfg->code_samples == kS8Cs && cfg->n_cyc == kS8Rows && want_matrix != 0;
         if (h->span8) {
             const size_t b2 = (size_t)(GPSMI_MAX_PRN + 1) * 2 * kS8Cs * sizeof(float);
             GPSMI_HIP(hipMalloc((void**)&h->d_code_eo, b2));
@@ -881,20 +926,22 @@ static int trk_build(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk* h) {
     P.nch = max_ch; P.df_no = 1024 / cfg->n_cyc; P.t_last = t32[ngps - 1];
     P.om_min = (float)(2.0 * M_PI * (double)cfg->min_freq);
     P.om_max = (float)(2.0 * M_PI * (double)cfg->max_freq);
-    const char* dbg = getenv("GPSMI_DEBUG_FLAGS");
-    P.flags = dbg ? atoi(dbg) : 0;
-    const char* cgs = getenv("GPSMI_CORR_CG");
-    if (cgs && (atoi(cgs) == 2 || atoi(cgs) == 4 || atoi(cgs) == 6)) h->corr_cg = atoi(cgs);
-    if (const char* dd = getenv("GPSMI_DONE_BY_DISPATCH")) h->done_by_dispatch = atoi(dd) != 0;
-    if (const char* im = getenv("GPSMI_STREAM_INLINE_MAX")) h->stream_inline_max = (size_t)atoll(im);
-    if (const char* cs1 = getenv("GPSMI_CORR_SMALL")) {
-        int a1 = 0, a2 = 0;
-        if (sscanf(cs1, "%d,%d", &a1, &a2) == 2 && a1 >= 0 && a2 >= a1) { h->corr_small1 = a1; h->corr_small2 = a2; }
+    // the tuning options (gpsmi_trk_set_option changes them on a live handle); their defaults come
+    // from gpsmi_set_default, else from the environment, else from the measurements quoted at the fields
+    long long v = 0;
+    default_opt("debug_flags", &v, 0);
+    P.flags = (int)v;
+    const struct { const char* key; long long fallback; } tun[] = {
+        {"corr_cg", h->corr_cg}, {"span_single_max", h->span_single_max}, {"stream_inline_max", (long long)h->stream_inline_max},
+        {"done_by_dispatch", h->done_by_dispatch}, {"corr_overlap", h->corr_overlap}};
+    for (const auto& t : tun) {
+        default_opt(t.key, &v, t.fallback);
+        if (v != t.fallback) (void)gpsmi_trk_set_option(h, t.key, v);   // (an out-of-range default is ignored)
     }
-    if (const char* sm = getenv("GPSMI_SPAN_SINGLE_MAX")) {
-        const int v = atoi(sm);
-        if (v >= 1 && v <= kSpanUnitsMax) h->span_single_max = v;
-    }
+    long long s1 = h->corr_small1, s2 = h->corr_small2;                 // (a pair: taken together)
+    default_opt("corr_small1", &s1, s1);
+    default_opt("corr_small2", &s2, s2);
+    if (s1 >= 0 && s2 >= s1 && s2 <= (1 << 24)) { h->corr_small1 = (int)s1; h->corr_small2 = (int)s2; }
     return trk_reserve(h, max_ch);
 }
 
@@ -911,7 +958,7 @@ int gpsmi_trk_destroy(gpsmi_trk* h) {
                     h->slot[1].d_partial, h->slot[0].d_out,
                     h->slot[1].d_out, h->d_fold,
                     h->d_mag, h->d_stats, h->d_xsel, h->d_rsel, h->d_partial_g, h->d_twN, h->d_RS,
-                    h->d_S, h->d_code2, h->d_code_eo, h->slot[0].d_rec, h->slot[1].d_rec, h->d_RSp};
+                    h->d_S, h->d_code_eo, h->slot[0].d_rec, h->slot[1].d_rec, h->d_RSp};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto& sl : h->slot) {
@@ -946,10 +993,6 @@ int gpsmi_trk_set_replica(gpsmi_trk* h, int prn, const float* replica, const flo
     GPSMI_HIP(hipMemcpy(h->d_code + (size_t)prn * cs, replica, cs * sizeof(float),
                         hipMemcpyHostToDevice));
     if (h->mfma) {
-        GPSMI_HIP(hipMemcpy(h->d_code2 + (size_t)prn * 2 * kFftN, replica, kFftN * sizeof(float),
-                            hipMemcpyHostToDevice));
-        GPSMI_HIP(hipMemcpy(h->d_code2 + (size_t)prn * 2 * kFftN + kFftN, replica,
-                            kFftN * sizeof(float), hipMemcpyHostToDevice));
         std::vector<float> eo(2 * kFftN);          // plane e of four, entry h = replica[(4 h + e) mod 2048], 1024 entries
         for (int e = 0; e < 4; ++e)
             for (int i = 0; i < kFftN / 2; ++i) eo[e * (kFftN / 2) + i] = replica[(4 * i + e) % kFftN];
@@ -989,6 +1032,7 @@ int gpsmi_trk_open(gpsmi_trk* h, int ch, int prn, float freq_hz, int delay) {
     st.prn = prn; st.delay = delay; st.freq = freq_hz; st.phase = 0.f;
     st.omega0 = (float)(2.0 * M_PI * (double)freq_hz);    // FREQ is a Python float here
     st.df_len = 1; st.df[0] = 0.f;
+    st.std_dev = 0.005f;                  // STD_DEV "overwritten by 1st stream" (gpslib.py:1074)
     h->h_state[ch] = st;
     h->state_dirty_host = true;
     return GPSMI_OK;
@@ -1023,6 +1067,7 @@ int gpsmi_trk_set_state(gpsmi_trk* h, int ch, const gpsmi_trk_state* st) {
     GPSMI_REQUIRE(st->delay >= 0 && st->delay < h->cfg.code_samples, "delay out of range");
     GPSMI_REQUIRE(st->nps >= 0 && st->nps <= h->cfg.code_samples, "nps out of range");
     GPSMI_REQUIRE(st->df_len >= 1 && st->df_len <= h->P.df_no, "df_len out of range");
+    GPSMI_REQUIRE(st->edge_state >= -1 && st->edge_state <= 2, "edge_state out of range");
     if (st->prn && !h->have_rep[st->prn])
         return fail(GPSMI_E_STATE, "no replica set for PRN %d", st->prn);
     GPSMI_HIP(hipSetDevice(h->cfg.device));
@@ -1041,6 +1086,7 @@ int gpsmi_trk_erase_prev(gpsmi_trk* h, int ch) {
     if (rc) return rc;
     h->h_state[ch].nps = 0;               // PREV_SAMPLES = [] (gpslib.py:1095-1099)
     h->h_state[ch].prev_sum_re = h->h_state[ch].prev_sum_im = 0.f;
+    h->h_state[ch].edge_state = 0;        // EDGES = [0]
     h->state_dirty_host = true;
     return GPSMI_OK;
 }
@@ -1204,7 +1250,8 @@ int gpsmi_trk_replay_load(gpsmi_trk* h, int nb, const gpsmi_trk_state* table,
         if (s.prn < 0 || s.prn > GPSMI_MAX_PRN || (s.prn && !h->have_rep[s.prn]))
             return fail(GPSMI_E_ARG, "replay table row %zu: bad PRN %d", j, s.prn);
         if (s.prn && (s.delay < 0 || s.delay >= h->cfg.code_samples || s.nps < 0 ||
-                      s.nps > h->cfg.code_samples || s.df_len < 1 || s.df_len > h->P.df_no))
+                      s.nps > h->cfg.code_samples || s.df_len < 1 || s.df_len > h->P.df_no ||
+                      s.edge_state < -1 || s.edge_state > 2))
             return fail(GPSMI_E_ARG, "replay table row %zu: state out of range", j);
         if (delay_used && delay_used[j] >= h->cfg.code_samples)
             return fail(GPSMI_E_ARG, "replay table row %zu: delay_used out of range", j);
@@ -1396,6 +1443,66 @@ int gpsmi_trk_set_streams(gpsmi_trk* h, int n_streams) {
     h->state_dirty_host = false;
     h->n_streams = n_streams;
     h->replay_nb = 0;
+    return GPSMI_OK;
+}
+
+int gpsmi_trk_set_option(gpsmi_trk* h, const char* key, long long value) {
+    GPSMI_REQUIRE(h && key, "null argument");
+    const auto bad = [&]() { return fail(GPSMI_E_ARG, "gpsmi_trk_set_option: %s = %lld out of range", key, value); };
+    if (!strcmp(key, "corr_cg")) {
+        if (value != 2 && value != 4 && value != 6) return bad();
+        h->corr_cg = (int)value;
+    } else if (!strcmp(key, "corr_small1")) {
+        if (value < 0 || value > h->corr_small2) return bad();
+        h->corr_small1 = (int)value;
+    } else if (!strcmp(key, "corr_small2")) {
+        if (value < h->corr_small1 || value > (1 << 24)) return bad();
+        h->corr_small2 = (int)value;
+    } else if (!strcmp(key, "span_single_max")) {
+        if (value < 1 || value > kSpanUnitsMax) return bad();
+        h->span_single_max = (int)value;
+    } else if (!strcmp(key, "stream_inline_max")) {
+        if (value < 0) return bad();
+        h->stream_inline_max = (size_t)value;
+    } else if (!strcmp(key, "done_by_dispatch")) {
+        h->done_by_dispatch = value != 0;
+    } else if (!strcmp(key, "corr_overlap")) {
+        h->corr_overlap = value != 0;
+    } else if (!strcmp(key, "correlator") || !strcmp(key, "codephase") || !strcmp(key, "debug_flags")) {
+        return fail(GPSMI_E_STATE, "gpsmi_trk_set_option: '%s' is taken at create time (gpsmi_set_default)", key);
+    } else {
+        return fail(GPSMI_E_ARG, "gpsmi_trk_set_option: unknown option '%s'", key);
+    }
+    return GPSMI_OK;
+}
+
+int gpsmi_trk_get_option(gpsmi_trk* h, const char* key, long long* value) {
+    GPSMI_REQUIRE(h && key && value, "null argument");
+    if (!strcmp(key, "corr_cg")) *value = h->corr_cg;
+    else if (!strcmp(key, "corr_small1")) *value = h->corr_small1;
+    else if (!strcmp(key, "corr_small2")) *value = h->corr_small2;
+    else if (!strcmp(key, "span_single_max")) *value = h->span_single_max;
+    else if (!strcmp(key, "stream_inline_max")) *value = (long long)h->stream_inline_max;
+    else if (!strcmp(key, "done_by_dispatch")) *value = h->done_by_dispatch;
+    else if (!strcmp(key, "corr_overlap")) *value = h->corr_overlap;
+    else if (!strcmp(key, "correlator")) *value = (h->mfma == 4 || h->span8) ? 1 : 0;     // what runs, not what was asked
+    else if (!strcmp(key, "codephase")) *value = h->general ? (h->pfa ? 0 : (h->big ? 2 : 1)) : 0;
+    else if (!strcmp(key, "debug_flags")) *value = h->P.flags;
+    else return fail(GPSMI_E_ARG, "gpsmi_trk_get_option: unknown option '%s'", key);
+    return GPSMI_OK;
+}
+
+int gpsmi_trk_corr_grid(int nblocks, int ngroups) {
+    if (nblocks < 1 || ngroups < 1) return fail(GPSMI_E_ARG, "gpsmi_trk_corr_grid: counts must be >= 1");
+    return corr_grid(nblocks, ngroups);
+}
+
+int gpsmi_trk_corr_wg_map(int nblocks, int ngroups, int wg, int* block, int* group) {
+    GPSMI_REQUIRE(block && group, "null argument");
+    GPSMI_REQUIRE(nblocks >= 1 && ngroups >= 1 && wg >= 0 && wg < corr_grid(nblocks, ngroups), "out of range");
+    const CorrWg u = corr_wg_map(wg, nblocks, ngroups);
+    *block = u.block;
+    *group = u.group;
     return GPSMI_OK;
 }
 

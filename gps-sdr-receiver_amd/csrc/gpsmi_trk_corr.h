@@ -20,6 +20,7 @@
 #include <type_traits>
 #include "gpsmi_fft.h"
 #include "gpsmi_stats.h"
+#include "gpsmi_wgmap.h"
 
 namespace gpsmi {
 
@@ -88,13 +89,9 @@ __global__ __launch_bounds__(256, (CG > 4 || CG == 1) ? 2 : 3) void trk_corr_ker
     __shared__ float2 vtab[CG][32];              // the factors of V(t), see the prologue
 
     // batches: the channel groups of a block are neighbours on one XCD (they share its rows through
-    // that L2).  A launch of fewer than 8 blocks (the closed loop) would leave 7 of 8 workgroups with
-    // nothing to do: its grid is exactly nblocks * ngroups and maps linearly.
-    const int wg = blockIdx.x;
-    const bool linear = (int)gridDim.x == nblocks * ngroups;
-    const int xcd = wg & 7, slot = wg >> 3;
-    const int g = linear ? wg % ngroups : slot % ngroups;
-    const int b = linear ? wg / ngroups : (slot / ngroups) * 8 + xcd;
+    // that L2); fewer than 8 blocks (the closed loop) map linearly: gpsmi_wgmap.h
+    const CorrWg unit = corr_wg_map((int)blockIdx.x, nblocks, ngroups);
+    const int g = unit.group, b = unit.block;
     if (b >= nblocks) return;
     const int t = threadIdx.x;
     const int cs = kFftN;

@@ -63,6 +63,7 @@ constexpr int kSpRowDw = 2 * kSpTile + 2;      // dwords per tile row: lane = (r
 constexpr int kSpTileFloats = 32 * kSpRowDw;
 constexpr int kSpWaveFloats = kSpTileFloats;                     // 4160 floats = 16,640 B per wave
 constexpr int kSpInf = 1 << 20;
+constexpr int kRsrcFlags = 0x00020000;         // raw buffer descriptor, 32-bit data format (gfx9)
 
 
 typedef float sp4 __attribute__((ext_vector_type(4)));
@@ -134,7 +135,7 @@ __device__ __forceinline__ void sp_load_tile(const void* blk, int pos, int lane,
     constexpr int CS = kFftN, NC = 32;
     if (FMT == 0) {
         const __amdgpu_buffer_rsrc_t blk_rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<void*>(blk), 0, CS * NC * (int)sizeof(float2), kMfRsrcFlags);
+            const_cast<void*>(blk), 0, CS * NC * (int)sizeof(float2), kRsrcFlags);
         const int ld_off = ((lane >> 5) * CS + 2 * (lane & 31)) * (int)sizeof(float2);
         const int tb = pos * (int)sizeof(float2);
 #pragma unroll
@@ -143,7 +144,7 @@ __device__ __forceinline__ void sp_load_tile(const void* blk, int pos, int lane,
                 blk_rs, ld_off, tb + i * (2 * CS * (int)sizeof(float2)), AUX));
     } else {
         const __amdgpu_buffer_rsrc_t blk_rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<void*>(blk), 0, CS * NC * 2, kMfRsrcFlags);
+            const_cast<void*>(blk), 0, CS * NC * 2, kRsrcFlags);
         const int ld_off = ((lane >> 3) * CS + 8 * (lane & 7)) * 2;
         const int tb = pos * 2;
 #pragma unroll
@@ -204,7 +205,7 @@ __device__ __forceinline__ void sp_swap_tile(float* tl, int lane, sp4 (&st)[16],
     constexpr int CS = kFftN, NC = 32;
     if (FMT == 0) {
         const __amdgpu_buffer_rsrc_t blk_rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<void*>(blk), 0, CS * NC * (int)sizeof(float2), kMfRsrcFlags);
+            const_cast<void*>(blk), 0, CS * NC * (int)sizeof(float2), kRsrcFlags);
         const int ld_off = ((lane >> 5) * CS + 2 * (lane & 31)) * (int)sizeof(float2);
         const int tb = pos * (int)sizeof(float2);
         const int swz = ((lane & 31) >> 3) & 1;              // (see sp_store_tile)
@@ -343,7 +344,7 @@ __device__ __forceinline__ void span_wave(const void* __restrict__ blk, const vo
     // entries (or for the registers they land in) never waits for rows.  The second half of the
     // tile goes straight to its place, the first half of the NEXT tile to a side buffer.
     const __amdgpu_buffer_rsrc_t code_rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(code_q4), 0, (GPSMI_MAX_PRN + 1) * 2 * CS * (int)sizeof(float), kMfRsrcFlags);
+        const_cast<float*>(code_q4), 0, (GPSMI_MAX_PRN + 1) * 2 * CS * (int)sizeof(float), kRsrcFlags);
     int cd_off;
     {
         const int r0 = (pos0 + k - d_c) & (CS - 1);

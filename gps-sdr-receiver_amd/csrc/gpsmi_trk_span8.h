@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void trk_span8_kernel(
     // ---- tile staging: 3 x b128 per lane; flat index L = lane + 64 i -> row L / 24, 16-byte piece L % 24
     const char* blk = reinterpret_cast<const char*>(iq) + (size_t)b * ((size_t)CS * kS8Rows * sizeof(float2));
     const __amdgpu_buffer_rsrc_t blk_rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(blk), 0, CS * kS8Rows * (int)sizeof(float2), kMfRsrcFlags);
+        const_cast<char*>(blk), 0, CS * kS8Rows * (int)sizeof(float2), kRsrcFlags);
     int ld_off[3], st_off[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void trk_span8_kernel(
     // e = (pi - d) & 1 and half index (r - e) / 2, which advances by one per pair: 24 consecutive
     // entries of plane e (doubled: never wraps).  A closed channel reads PRN slot 0 (zeros).
     const __amdgpu_buffer_rsrc_t code_rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(code_eo), 0, (GPSMI_MAX_PRN + 1) * 2 * CS * (int)sizeof(float), kMfRsrcFlags);
+        const_cast<float*>(code_eo), 0, (GPSMI_MAX_PRN + 1) * 2 * CS * (int)sizeof(float), kRsrcFlags);
     const int s_d = smd.active ? smd.delay_used : 0;
     const int s_e = (spl - s_d) & 1;
     const int s_plane = ((smd.active ? smd.prn : 0) * 2 + s_e) * CS;

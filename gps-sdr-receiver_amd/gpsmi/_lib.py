@@ -38,7 +38,9 @@ STATE_DTYPE = np.dtype([
     ('phase', np.float32), ('phase_locked', np.int32), ('nps', np.int32),
     ('prev_sum_re', np.float32), ('prev_sum_im', np.float32),
     ('df_len', np.int32), ('omega0', np.float32),
-    ('df', np.float32, (MAX_DF,))])
+    ('df', np.float32, (MAX_DF,)),
+    ('edge_state', np.int32), ('prev_signal', np.float32), ('std_dev', np.float32),
+    ('reserved', np.int32)])
 
 OUT_DTYPE = np.dtype([
     ('prn', np.int32), ('n_dumps', np.int32),
@@ -49,7 +51,9 @@ OUT_DTYPE = np.dtype([
     ('code_phase', np.float64), ('delay_used', np.int32),
     ('std_dev', np.float32), ('amplitude', np.float32), ('df', np.float32),
     ('phase_shift', np.float32), ('freq', np.float32), ('phase', np.float32),
-    ('phase_locked', np.int32), ('nps', np.int32), ('reserved1', np.int32)],
+    ('phase_locked', np.int32), ('nps', np.int32),
+    ('edge_mask', np.uint32), ('edge_mask_hi', np.uint32), ('edge_sign0', np.int32),
+    ('ms_count', np.int32)],
     align=True)
 
 EXPORTS = [
@@ -76,6 +80,8 @@ EXPORTS = [
     'gpsmi_acq_set_input_format',
     'gpsmi_comm_unique_id', 'gpsmi_comm_create', 'gpsmi_comm_destroy',
     'gpsmi_comm_allgather_peaks', 'gpsmi_comm_count',
+    'gpsmi_set_default', 'gpsmi_clear_default', 'gpsmi_trk_set_option', 'gpsmi_trk_get_option',
+    'gpsmi_trk_corr_grid', 'gpsmi_trk_corr_wg_map',
 ]
 
 _lib = None
@@ -157,6 +163,12 @@ def load():
         'gpsmi_comm_destroy': [vp],
         'gpsmi_comm_allgather_peaks': [vp, vp, vp, C.c_int, vp],
         'gpsmi_comm_count': [vp, P(C.c_int), P(C.c_int)],
+        'gpsmi_set_default': [C.c_char_p, C.c_longlong],
+        'gpsmi_clear_default': [C.c_char_p],
+        'gpsmi_trk_set_option': [vp, C.c_char_p, C.c_longlong],
+        'gpsmi_trk_get_option': [vp, C.c_char_p, P(C.c_longlong)],
+        'gpsmi_trk_corr_grid': [C.c_int, C.c_int],
+        'gpsmi_trk_corr_wg_map': [C.c_int, C.c_int, C.c_int, P(C.c_int), P(C.c_int)],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)

@@ -42,6 +42,15 @@ class Config:
                         self.max_freq, self.device)
 
 
+def set_default(key, value):
+    """Process-wide default of a create-time / tuning option (gpsmi_set_default, gpsmi.h)."""
+    check(_lib.load().gpsmi_set_default(key.encode(), int(value)), 'gpsmi_set_default')
+
+
+def clear_default(key):
+    check(_lib.load().gpsmi_clear_default(key.encode()), 'gpsmi_clear_default')
+
+
 def device_count():
     n = C.c_int(0)
     check(_lib.load().gpsmi_device_count(C.byref(n)), 'gpsmi_device_count')
@@ -325,6 +334,8 @@ class TrkEngine:
         n = self.streams * self.cfg.ngps
         if iq.size != n or iq.dtype != (np.uint16 if getattr(self, 'raw_u8', False) else np.complex64):
             raise TypeError('block size or dtype does not match the handle')
+        if not iq.flags.c_contiguous:
+            raise ValueError('the block must be C-contiguous (its address is handed to the device)')
         check(self.lib.gpsmi_trk_process_stream(self.h, ptr(iq), n, ptr(out)),
               'gpsmi_trk_process_stream')
 
@@ -380,6 +391,15 @@ class TrkEngine:
         check(self.lib.gpsmi_trk_set_input_format(self.h, 1 if raw_u8 else 0),
               'gpsmi_trk_set_input_format')
         self.raw_u8 = bool(raw_u8)
+
+    def set_option(self, key, value):
+        """A tuning option of this handle (gpsmi_trk_set_option; the keys are listed in gpsmi.h)."""
+        check(self.lib.gpsmi_trk_set_option(self.h, key.encode(), int(value)), 'gpsmi_trk_set_option')
+
+    def get_option(self, key):
+        v = C.c_longlong(0)
+        check(self.lib.gpsmi_trk_get_option(self.h, key.encode(), C.byref(v)), 'gpsmi_trk_get_option')
+        return v.value
 
     def set_timing(self, on):
         """Kernel-timing events for the launches that follow (see gpsmi.h)."""

@@ -119,7 +119,11 @@ class StreamedInput:
         # so that step is complete -- see the contract in include/gpsmi.h)
         j = self.k % len(self.ring)
         slot = self.ring[j]
-        slot.array[...] = np.asarray(block).reshape(slot.array.shape)
+        block = np.asarray(block)
+        if block.dtype != slot.array.dtype:    # a silent cast would turn one format into garbage of the other
+            raise TypeError(f'block dtype {block.dtype} does not match the handle\'s input format '
+                            f'({slot.array.dtype.name}; see TrkEngine.set_input_format)')
+        slot.array[...] = block.reshape(slot.array.shape)
         self.trk.process_stream(slot.array, self.outs[j].array if self.keep else None)
         self.k += 1
         if self.keep and self.k - self.taken > 2:

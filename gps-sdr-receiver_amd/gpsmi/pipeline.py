@@ -51,6 +51,7 @@ class Receiver:
     def command(self, msg):
         """b'SWEEP' restarts the cold search, b'STOP' ends the run."""
         if msg == b'SWEEP':
+            self.drain()                             # (cpQLst must be current for getNewSats)
             self._start_sweep(first=False)
         elif msg == b'STOP':
             self.running = False
@@ -76,20 +77,44 @@ class Receiver:
                     self.pool, self.pool_no, self.pool_worker, self.act_sat_set, new,
                     self.found_sats)
             return None
-        res_lst = R.satCalc(self.act_sat_set, self.pool, self.pool_worker, data,
-                            self.smp_time)
-        return self.hand_off(res_lst)
+        if not self.act_sat_set:                     # (nothing acquired: the reference's satCalc
+            return None                              # returns [], no datagram)
+        # the block is enqueued on the GPU; the host catches up once a second, at the block
+        # the reference sends its datagram on (R.satCalcLazy)
+        res = None
+        for batch in R.satCalcLazy(self.act_sat_set, self.pool, self.pool_worker, data,
+                                   self.smp_time):
+            res = self.hand_off(batch) or res
+        return res
 
-    def hand_off(self, res_lst):
-        """gpsrecv.py:496-519: merge the channel results; when any frame exists
-        (once a second) build the datagram and reset the accumulators."""
+    def drain(self):
+        """Absorb the blocks that are still on their way (before anything that reads the
+        channel state from outside: a command, close, a test)."""
+        self.pool.absorb_pending()
+        for batch in self.pool.take_done():
+            self.hand_off(batch)
+
+    def hand_off(self, batch):
+        """gpsrecv.py:496-519 for the K blocks of a batch, the last of which carries the
+        frames: every block appends (streamNo, coPh) for the channels that correlated -- a
+        satellite enters coPhLst at its first such block, in the order satCalc returned the
+        results -- and when any frame exists (once a second) the datagram is built and the
+        accumulators are reset."""
+        ngps = self.cfg.ngps
+        cp = batch.code_phase                        # [K][satellites in actSatSet order]
+        good = cp >= 0
+        stream_nos = [t // ngps for t in batch.smp_times]
+        first = np.where(good.any(axis=0), good.argmax(axis=0), len(stream_nos))
+        for col in np.argsort(first, kind='stable').tolist():
+            if first[col] == len(stream_nos):
+                break
+            lst = self.co_ph_lst.setdefault(batch.sats[col], [])
+            for k in np.flatnonzero(good[:, col]).tolist():
+                lst.append((stream_nos[k], float(cp[k, col])))
         frame_lst = []
-        stream_no = self.smp_time // self.cfg.ngps
-        for sw_fq, sat_no, f_lst, co_ph, cp_q in res_lst:
+        for sw_fq, sat_no, f_lst, co_ph, cp_q in batch.res:
             frame_lst += f_lst
             self.cp_q_lst[sat_no] = cp_q
-            if co_ph >= 0:
-                self.co_ph_lst.setdefault(sat_no, []).append((stream_no, co_ph))
         if not frame_lst:
             return None
         res = pickle.dumps((self.skipped_data, frame_lst, self.co_ph_lst))
@@ -99,6 +124,7 @@ class Receiver:
         return res
 
     def close(self):
+        self.drain()
         R.closeMultiProcPool(self.pool)
         self.acq.engine.close()
 

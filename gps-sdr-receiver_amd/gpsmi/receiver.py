@@ -11,16 +11,30 @@ and ``satCalc`` is one ``gpsmi_trk_process`` call per block; the functions keep
 the reference's names, arguments and return shapes so that ``processData``
 (gpsrecv.py:445-548) can call them unchanged.
 
-``HostChannel`` consumes one engine output record per block and reproduces
-what ``SatStream.process`` returns: ``(SWEEP, frameLst, codePhase,
-(CORR_Q, CORR_L))``.  The engine has already done demodDoppler, cacodeCorr,
-fitCodePhase, decodeData's sums, the statistics and the PLL.
+``HostChannel`` consumes the engine's output records and reproduces what
+``SatStream.process`` returns: ``(SWEEP, frameLst, codePhase, (CORR_Q, CORR_L))``.
+The engine has already done demodDoppler, cacodeCorr, fitCodePhase, decodeData's
+sums AND its edge scan (the sign / hysteresis rule of gpslib.py:1421-1436 runs in
+the device epilogue, the record carries a bit mask of the dumps that are edges),
+the statistics and the PLL; what is left here is list bookkeeping.
+
+Nothing the host does between two report blocks (``streamNo % NO_SEC == 0``,
+once a second) feeds back into the tracking loop -- the loop is closed on the
+device -- so the records of up to a second of blocks can be absorbed in one
+vectorised pass: ``satCalcLazy`` enqueues a block without waiting for it
+(``gpsmi_trk_process_stream``: page-locked input ring, page-locked record ring)
+and absorbs everything that is pending when a report block, a sweep, a stream gap
+or any other pool operation needs the host state; ``satCalc`` is the same with a
+batch of one (the reference's per-block call).
 """
+from collections import deque
+from itertools import islice
+
 import numpy as np
 
 from . import navbits
 from .acquisition import norm_max_corr
-from .engine import AcqEngine, Config, TrkEngine, dumps_of
+from .engine import OUT_DTYPE, AcqEngine, Config, PinnedArray, TrkEngine
 
 MIN_CORR_Q = -0.9                      # gpslib.py:1048
 
@@ -57,7 +71,7 @@ class HostChannel:
         self.CORR_Q = 0
         self.CORR_L = 0
         self.CORRLST_NO = 60 * self.NO_SEC
-        self.CORRLST = [0]
+        self._corr_reset()
         self.REP_SWEEP = False
         self.nps = 0                        # len(PREV_SAMPLES) before the block
         self.FREQ_SAVE = freq
@@ -70,9 +84,15 @@ class HostChannel:
         self.GPSBITS_ST = np.array([], dtype=np.int64)
         self.nps = 0
 
+    def _corr_reset(self):
+        # CORRLST (gpslib.py:1085-1087) as a bounded deque: append drops the oldest entry, which is
+        # ``del CORRLST[0]`` of corrQuality; the sum of its entries is carried along
+        self.CORRLST = deque([0], maxlen=self.CORRLST_NO)
+        self._corr_sum = 0
+
     def setPhaseUnlocked(self):
         self.PHASE_LOCKED = False
-        self.CORRLST = [0]
+        self._corr_reset()
         self.MS_TIME = 0
         self.erasePrevData()
 
@@ -90,38 +110,20 @@ class HostChannel:
         return len(self.CORRLST) >= self.CORRLST_NO and self.CORR_Q < MIN_CORR_Q
 
     def corrQuality(self, code_phase):      # gpslib.py:1331-1339
-        self.CORRLST.append(-1 if code_phase < 0 else 1)
-        if len(self.CORRLST) > self.CORRLST_NO:
-            del self.CORRLST[0]
-        return np.mean(self.CORRLST), np.mean(self.CORRLST[-self.NO_SEC:])
+        return self.corrQualityMany([-1 if code_phase < 0 else 1])
 
-    # ---- edge detection of decodeData (gpslib.py:1394-1398, :1408-1436)
-    def detect_edges(self, dumps, delay):
-        cs = self.cfg.code_samples
-        min_edge_amp = 3 * self.STD_DEV
-        prev_sign = (2 * (len(self.EDGES) % 2) - 1) * self.EDGES[0]
-        n1 = self.nps + delay
-        if n1 == 0:
-            n1 = cs
-            st = self.SMP_TIME
-        else:
-            st = self.SMP_TIME + delay - cs
-        n0 = 0
-        for m in dumps:
-            if self.PHASE_LOCKED:
-                re = np.float32(m.real)
-                sgn = np.sign(re)
-                if self.EDGES[0] == 0:
-                    self.EDGES[0] = sgn
-                    prev_sign = sgn
-                elif (sgn != prev_sign and prev_sign * self.PREV_SIGNAL > 0
-                      and abs(re - self.PREV_SIGNAL) > min_edge_amp):
-                    self.EDGES.append((self.MS_TIME, st + n0))
-                    prev_sign = sgn
-                self.PREV_SIGNAL = re
-                self.MS_TIME += 1
-            n0 = n1
-            n1 += cs
+    def corrQualityMany(self, vals):
+        """corrQuality for consecutive blocks (vals: +1 / -1 per block) -> (CORR_Q, CORR_L) after
+        the last one: means over the last CORRLST_NO / NO_SEC entries.  Sums of +-1 are exact, so
+        sum / len is np.mean's value bit for bit."""
+        d = self.CORRLST
+        n_drop = len(d) + len(vals) - d.maxlen
+        if n_drop > 0:
+            self._corr_sum -= sum(islice(d, 0, n_drop))
+        d.extend(vals)
+        self._corr_sum += sum(vals)
+        m = min(len(d), self.NO_SEC)
+        return self._corr_sum / len(d), sum(islice(reversed(d), 0, m)) / m
 
     # ---- edge list -> 20-ms bits (gpslib.py:1451-1492)
     def logicalBits(self):
@@ -154,15 +156,53 @@ class HostChannel:
     # ---- the tracking branch of process() after the GPU work (gpslib.py:1178-1208)
     def absorb(self, rec, smp_time):
         """rec: one gpsmi_trk_out record of this channel for the block."""
-        self.SMP_TIME = smp_time
-        stream_no = smp_time // self.cfg.ngps
-        code_phase = float(rec['code_phase'])
-        self.CORR_Q, self.CORR_L = self.corrQuality(code_phase)
-        self.DELAY = int(rec['delay_used'])
-        self.detect_edges(dumps_of(rec), self.DELAY)
-        self.STD_DEV = rec['std_dev']
-        self.AMPLITUDE = rec['amplitude']
-        self.MAX_CORR = rec['norm_max_corr']
+        recs = np.empty(1, dtype=rec.dtype)
+        recs[0] = rec
+        trig, frames, cps = self.absorb_many(recs, [smp_time])
+        return trig, frames, cps[0]
+
+    def absorb_many(self, recs, smp_times):
+        """recs: the records of this channel for K consecutive tracking blocks (a 1-D structured
+        array), smp_times their SMP_TIMEs.  Only the last block may be a report block (the caller
+        absorbs at every one).  -> (sweep trigger, frameLst of the last block, [codePhase] * K)."""
+        cfg = self.cfg
+        cs = cfg.code_samples
+        k_last = len(recs) - 1
+        cps = recs['code_phase'].tolist()
+        self.CORR_Q, self.CORR_L = self.corrQualityMany([-1 if v < 0 else 1 for v in cps])
+        # decodeData's edges (gpslib.py:1421-1436) from the device's scan: bit i of a record's mask
+        # = dump i is an edge, at (MS_TIME before the block + i, ST + n0 of window i)
+        msc = recs['ms_count']
+        if msc.any():                                   # PHASE_LOCKED was set before some block
+            events = np.flatnonzero((recs['edge_mask'] != 0) | (recs['edge_mask_hi'] != 0)
+                                    | (recs['edge_sign0'] != 0))
+            for j in events.tolist():
+                r = recs[j]
+                if self.EDGES[0] == 0 and r['edge_sign0'] != 0:
+                    self.EDGES[0] = np.float32(r['edge_sign0'])     # np.sign(m.real), :1424-1426
+                mask = int(r['edge_mask']) | (int(r['edge_mask_hi']) << 32)
+                if mask:
+                    ms0 = self.MS_TIME + int(msc[:j].sum())
+                    delay = int(r['delay_used'])
+                    nps = int(recs[j - 1]['nps']) if j else self.nps
+                    first = int(r['first_len'])                     # n1 of the first window
+                    st = smp_times[j] if nps + delay == 0 else smp_times[j] + delay - cs
+                    while mask:
+                        i = (mask & -mask).bit_length() - 1
+                        mask &= mask - 1
+                        self.EDGES.append((ms0 + i, st + (first + (i - 1) * cs if i else 0)))
+            self.MS_TIME += int(msc.sum())
+        last = recs[k_last]
+        self.SMP_TIME = smp_times[k_last]
+        stream_no = self.SMP_TIME // cfg.ngps
+        self.DELAY = int(last['delay_used'])
+        self.STD_DEV = last['std_dev']
+        self.AMPLITUDE = last['amplitude']
+        self.MAX_CORR = last['norm_max_corr']
+        if k_last:                                      # the lock flag and FREQ the report sees are
+            prev = recs[k_last - 1]                     # those before the last block's PLL (:1192-1208)
+            self.PHASE_LOCKED = bool(prev['phase_locked'])
+            self.FREQ = prev['freq']
         frames, sweep = [], False
         if stream_no % self.NO_SEC == 0:
             if self.PHASE_LOCKED:
@@ -171,16 +211,27 @@ class HostChannel:
                 frames = [{}]
             self.reportValues(frames)
             sweep = self.checkCorrQuality()
-        self.nps = int(rec['nps'])
+        self.nps = int(last['nps'])
         if not sweep:
-            self.PHASE_LOCKED = bool(rec['phase_locked'])
-            self.FREQ = rec['freq']
-        return sweep, frames, code_phase
+            self.PHASE_LOCKED = bool(last['phase_locked'])
+            self.FREQ = last['freq']
+        return sweep, frames, cps
+
+
+class Batch:
+    """What absorbing K pending blocks yields: `res` = the reference's result list of the LAST
+    block ([(swFq, satNo, frameData, coPh, cpQ)] in actSatSet order), and for the hand-off the
+    code phases of all K blocks: `sats` (that order), `smp_times` [K], `code_phase` [K][len(sats)]."""
+
+    def __init__(self, res, sats, smp_times, code_phase):
+        self.res, self.sats, self.smp_times, self.code_phase = res, sats, smp_times, code_phase
 
 
 class GpuPool:
     """What ``initMultiProcPool`` returns as `pool`: one tracking engine and one
     acquisition engine (for per-channel re-sweeps) instead of a process list."""
+
+    RING = 64                               # record rows (blocks that may be pending at most)
 
     def __init__(self, pool_no, cfg=None, raw_u8=False, trk=None):
         self.cfg = cfg or Config()
@@ -189,7 +240,16 @@ class GpuPool:
         if self.raw_u8:
             self.trk.set_input_format(True)
         self.acq = None
+        self.pool_no = pool_no
         self.chan = [None] * pool_no        # HostChannel per worker slot
+        # blocks enqueued on the engine and not yet absorbed: [(smpTime, record row)], all for the
+        # same channel order `pending_order` [(satNo, slot)]
+        self.pending, self.pending_order = [], None
+        self.done = []                      # batches absorbed on the side (by a pool operation
+                                            # that needed the host state), for the next satCalcLazy
+        self.streamed = hasattr(self.trk, 'process_stream')
+        self.in_ring, self.out_ring, self.n_fed = None, None, 0
+        self.rows = [None] * self.RING      # (a stand-in engine's records, tests)
 
     def acq_engine(self):
         if self.acq is None:
@@ -198,7 +258,74 @@ class GpuPool:
                 self.acq.set_input_format(True)
         return self.acq
 
+    # ---- enqueue one block for all open channels, no wait
+    def submit(self, data, smp_time, order):
+        if len(self.pending) == self.RING:
+            self.absorb_pending()
+        row = (self.pending[-1][1] + 1) % self.RING if self.pending else 0
+        if self.streamed:
+            want = np.uint16 if self.raw_u8 else np.complex64
+            if self.in_ring is None:
+                # three page-locked input buffers: gpsmi_trk_process_stream returns once the step
+                # before last is done, so the buffer of the call three back is free (gpsmi.h)
+                self.in_ring = [PinnedArray((self.cfg.ngps,), want) for _ in range(3)]
+                self.out_ring = PinnedArray((self.RING, self.pool_no), OUT_DTYPE)
+            data = np.asarray(data)
+            if data.dtype != want:          # a silent cast would turn one format into garbage of the other
+                raise TypeError(f'block dtype {data.dtype} does not match the input format '
+                                f'({np.dtype(want).name})')
+            buf = self.in_ring[self.n_fed % 3].array
+            np.copyto(buf, data.reshape(buf.shape))
+            self.trk.process_stream(buf, self.out_ring.array[row])
+            self.n_fed += 1
+        else:
+            self.rows[row] = self.trk.process(data)
+        self.pending.append((smp_time, row))
+        self.pending_order = order
+
+    # ---- everything that is pending -> host state; the batch goes to `done`
+    def absorb_pending(self):
+        if not self.pending:
+            return
+        k = len(self.pending)
+        smp = [t for t, _ in self.pending]
+        rows = [r for _, r in self.pending]
+        if self.streamed:
+            self.trk.wait()
+            lo = rows[0]
+            recs = (self.out_ring.array[lo:lo + k] if lo + k <= self.RING
+                    else self.out_ring.array[rows])
+        else:
+            recs = np.stack([self.rows[r] for r in rows])
+        order = self.pending_order
+        self.pending, self.pending_order = [], None
+        res, trig = [], []
+        cp = np.empty((k, len(order)))
+        for col, (sno, wno) in enumerate(order):
+            hc = self.chan[wno]
+            t, frames, cps = hc.absorb_many(recs[:, wno], smp)
+            cp[:, col] = cps
+            if t:
+                trig.append(wno)
+            res.append([hc, sno, frames, cps[-1]])
+        for wno in trig:                                # initSweep (gpslib.py:1110-1116) with the
+            initSweep(self, wno, self.saved.pop(wno))   # state before this block's PLL update
+        self.done.append(Batch([(hc.SWEEP, sno, fr, c, (hc.CORR_Q, hc.CORR_L)) for hc, sno, fr, c in res],
+                               [sno for sno, _ in order], smp, cp))
+
+    saved = None
+
+    def take_done(self):
+        out, self.done = self.done, []
+        return out
+
     def close(self):
+        self.pending = []
+        if self.streamed and self.in_ring is not None:
+            self.trk.wait()
+            for p in self.in_ring + [self.out_ring]:
+                p.free()
+            self.in_ring = self.out_ring = None
         self.trk.close()
         if self.acq is not None:
             self.acq.close()
@@ -217,6 +344,7 @@ def closeMultiProcPool(pool):               # gpsrecv.py:363-367
 
 def open_worker(pool, wno, sat_no, freq, delay):
     """('initInst',(satNo,freq,delay)) for worker slot wno (gpsrecv.py:312-321)."""
+    pool.absorb_pending()
     pool.trk.open(wno, sat_no, freq, delay)
     pool.chan[wno] = HostChannel(sat_no, freq, delay, pool.cfg)
     return sat_no
@@ -224,6 +352,7 @@ def open_worker(pool, wno, sat_no, freq, delay):
 
 def close_worker(pool, wno):
     """('delInst',None) (gpsrecv.py:323-328) -> whether an instance existed."""
+    pool.absorb_pending()
     had = pool.chan[wno] is not None
     if had and not pool.chan[wno].SWEEP:
         pool.trk.close_channel(wno)
@@ -284,6 +413,7 @@ def initSweep(pool, wno, st=None):
     """SatStream.initSweep (gpslib.py:1110-1116) for the channel in worker slot wno:
     remember FREQ and DF (st: the engine state to fall back to, default the current
     one), unlock, restart at MIN_FREQ; the engine channel is closed until the sweep ends."""
+    pool.absorb_pending()
     hc = pool.chan[wno]
     if st is None:
         st = pool.trk.get_state(wno)
@@ -296,11 +426,10 @@ def initSweep(pool, wno, st=None):
     pool.trk.close_channel(wno)
 
 
-def satCalc(actSatSet, pool, poolWorker, data, smpTime, sweep=()):
-    """gpsrecv.py:404-417 -> [(swFq, satNo, frameData, coPh, cpQ), ...] in the
-    iteration order of actSatSet, one engine call for all tracking channels.
-    sweep: satellites whose channel is to start a sweep with this block, the
-    ``sweep=True`` argument of SatStream.process (gpslib.py:1141, :1147-1151)."""
+def _sat_calc(actSatSet, pool, poolWorker, data, smpTime, sweep=()):
+    """One block for every active satellite, waited for: tracking channels through the engine,
+    sweeping ones through the acquisition engine -> Batch of one block."""
+    pool.absorb_pending()                               # (earlier lazy blocks go to pool.done)
     cfg = pool.cfg
     stream_no = smpTime // cfg.ngps
     order = [(sno, poolWorker.index(sno)) for sno in actSatSet]
@@ -318,40 +447,92 @@ def satCalc(actSatSet, pool, poolWorker, data, smpTime, sweep=()):
         if (not hc.SWEEP and stream_no % hc.NO_SEC == 0
                 and len(hc.CORRLST) + 1 >= hc.CORRLST_NO):
             saved[wno] = pool.trk.get_state(wno)
-    out = pool.trk.process(data) if any(not pool.chan[w].SWEEP for _, w in order) \
-        else None
+    tracking = [(sno, wno) for sno, wno in order if not pool.chan[wno].SWEEP]
+    tracked = {}
+    if tracking:
+        # The engine advances every open channel.  A call for a SUBSET of the instances (the
+        # reference's workers are independent: a parent may run some of them on a block and
+        # the others later) must leave the rest untouched: their state rows are put back.
+        asked = {wno for _, wno in order}
+        others = {w: pool.trk.get_state(w) for w, hc in enumerate(pool.chan)
+                  if hc is not None and not hc.SWEEP and w not in asked}
+        n_done = len(pool.done)
+        pool.saved = saved
+        pool.submit(data, smpTime, tracking)
+        pool.absorb_pending()
+        tracked = {r[1]: r for r in pool.done.pop(n_done).res}
+        for w, st in others.items():
+            pool.trk.set_state(w, st)
     res = []
     for sno, wno in order:
         hc = pool.chan[wno]
-        if hc.SWEEP:                                    # gpslib.py:1153-1173
-            hc.SMP_TIME = smpTime
-            hc.REP_SWEEP = True
-            hc.SWEEP, hc.FREQ, hc.MAX_CORR, delay, code_phase = \
-                _sweep_frequency(pool, hc, data)
-            hc.CORR_Q, hc.CORR_L = hc.corrQuality(code_phase)
-            if delay >= 0:
-                hc.DELAY = delay
-            elif not hc.SWEEP:
-                hc.FREQ = hc.FREQ_SAVE                  # restoreFreq
-            if not hc.SWEEP:                            # back to tracking next block
-                pool.trk.open(wno, sno, hc.FREQ, hc.DELAY)
-                if delay < 0:                           # restoreFreq: FREQ_SAVE and DF_SAVE
-                    st = pool.trk.get_state(wno)
-                    n = len(hc.DF_SAVE)
-                    st['df_len'] = n
-                    st['df'][:n] = hc.DF_SAVE
-                    if isinstance(hc.FREQ_SAVE, np.float32):
-                        # FREQ is float32 again: the reference's next demodDoppler forms
-                        # float32(2 pi) * FREQ in float32, which the kernel does for omega0 == 0
-                        st['omega0'] = 0.0
-                    pool.trk.set_state(wno, st)
-            frames = []
-            if stream_no % hc.NO_SEC == 0:
-                frames = [{}]
-                hc.reportValues(frames)
-        else:
-            trig, frames, code_phase = hc.absorb(out[wno], smpTime)
-            if trig:                                    # initSweep (gpslib.py:1110-1116) with the
-                initSweep(pool, wno, saved[wno])        # state before this block's PLL update
+        if sno in tracked:
+            res.append(tracked[sno])
+            continue
+        hc.SMP_TIME = smpTime                           # gpslib.py:1153-1173
+        hc.REP_SWEEP = True
+        hc.SWEEP, hc.FREQ, hc.MAX_CORR, delay, code_phase = \
+            _sweep_frequency(pool, hc, data)
+        hc.CORR_Q, hc.CORR_L = hc.corrQuality(code_phase)
+        if delay >= 0:
+            hc.DELAY = delay
+        elif not hc.SWEEP:
+            hc.FREQ = hc.FREQ_SAVE                      # restoreFreq
+        if not hc.SWEEP:                                # back to tracking next block
+            pool.trk.open(wno, sno, hc.FREQ, hc.DELAY)
+            if delay < 0:                               # restoreFreq: FREQ_SAVE and DF_SAVE
+                st = pool.trk.get_state(wno)
+                n = len(hc.DF_SAVE)
+                st['df_len'] = n
+                st['df'][:n] = hc.DF_SAVE
+                if isinstance(hc.FREQ_SAVE, np.float32):
+                    # FREQ is float32 again: the reference's next demodDoppler forms
+                    # float32(2 pi) * FREQ in float32, which the kernel does for omega0 == 0
+                    st['omega0'] = 0.0
+                pool.trk.set_state(wno, st)
+        frames = []
+        if stream_no % hc.NO_SEC == 0:
+            frames = [{}]
+            hc.reportValues(frames)
         res.append((hc.SWEEP, sno, frames, code_phase, (hc.CORR_Q, hc.CORR_L)))
-    return res
+    return Batch(res, [sno for sno, _ in order], [smpTime], np.array([[r[3] for r in res]], dtype=np.float64))
+
+
+def satCalc(actSatSet, pool, poolWorker, data, smpTime, sweep=()):
+    """gpsrecv.py:404-417 -> [(swFq, satNo, frameData, coPh, cpQ), ...] in the
+    iteration order of actSatSet, one engine call for all tracking channels.
+    sweep: satellites whose channel is to start a sweep with this block, the
+    ``sweep=True`` argument of SatStream.process (gpslib.py:1141, :1147-1151)."""
+    return _sat_calc(actSatSet, pool, poolWorker, data, smpTime, sweep).res
+
+
+def satCalcLazy(actSatSet, pool, poolWorker, data, smpTime):
+    """satCalc without the wait: the block is enqueued behind the ones before it and the call
+    returns the batches that became complete -- [] for most blocks, at a report block
+    (``streamNo % NO_SEC == 0``, where the reference sends its datagram) one Batch holding that
+    block's result list and the code phases of every block since the last one.  A block that needs
+    a host decision (a channel in its sweep, a stream gap, a possible sweep trigger) takes the
+    per-block path of satCalc; the results are the same either way."""
+    cfg = pool.cfg
+    stream_no = smpTime // cfg.ngps
+    order = [(sno, poolWorker.index(sno)) for sno in actSatSet]
+    report = stream_no % (1024 // cfg.n_cyc) == 0
+    plain = len(order) > 0 and (pool.pending_order is None or pool.pending_order == order)
+    if plain:
+        n_pend = len(pool.pending)
+        for _, wno in order:
+            hc = pool.chan[wno]
+            if (hc.SWEEP or stream_no - 1 != hc.PREV_STREAM_NO
+                    or (report and len(hc.CORRLST) + n_pend + 1 >= hc.CORRLST_NO)):
+                plain = False
+                break
+    if not plain:
+        b = _sat_calc(actSatSet, pool, poolWorker, data, smpTime)
+        return pool.take_done() + [b]
+    for _, wno in order:
+        pool.chan[wno].PREV_STREAM_NO = stream_no
+    pool.saved = {}
+    pool.submit(data, smpTime, order)
+    if report:
+        pool.absorb_pending()
+    return pool.take_done()

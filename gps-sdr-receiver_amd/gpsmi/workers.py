@@ -14,9 +14,18 @@ tracking engine, and the ``runInst`` messages of a block -- the parent's ``satCa
 (gpsrecv.py:404-417) puts one into every active worker's queue before it reads any
 answer -- are collected and run as ONE ``gpsmi_trk_process`` call; each worker's answer
 goes to its own ``outQ`` in the reference's tuple.  The parent-side functions of the
-reference (``initMultiProcPool`` ... ``satCalc``) work unchanged on the pool this module
-returns, because the traffic on the queues is the same; they are restated below
-(``q_*``) for a host that does not import the reference.
+reference (``initMultiProcPool`` ... ``satCalc``, ``closeMultiProcPool`` with its
+put('done') / join() / close() per worker in turn) work unchanged on the pool this module
+returns, because the traffic on the queues is the same and every worker has a handle of its
+own whose join() returns when that worker's 'done' has been consumed; they are restated
+below (``q_*``) for a host that does not import the reference.
+
+Message timing never changes results (the reference's workers are independent processes):
+a burst that covers only some of the instances -- the grace period ran out, or another
+message closed it -- runs those channels only, the state of the others is put back
+(``receiver._sat_calc``), and their late ``runInst`` for the same block runs them then.
+An exception inside the loop is sent to every worker's ``outQ`` (a parent blocked in
+``outQ.get()`` gets the exception object instead of hanging) before the loop ends.
 
 ``gpsmi.receiver`` has the same functions as direct calls (no queues, no thread); this
 module is for a parent that wants to keep the reference's message boundary.
@@ -39,6 +48,7 @@ class WorkerLoop:
         self.grace = grace                     # s to wait for the rest of a block's runInst burst
         self.worker_no = [None] * len(self.pairs)
         self.sat = [0] * len(self.pairs)       # PRN per worker slot, 0 = no instance
+        self.done = [threading.Event() for _ in self.pairs]   # worker w has consumed its 'done'
         self._inbox = queue.Queue()
 
     def _forward(self, wno, in_q):
@@ -102,18 +112,26 @@ class WorkerLoop:
                     out_q.put(done)
                 elif kind == 'done':
                     alive -= 1
+                    self.done[wno].set()
+        except BaseException as err:           # a parent blocked in outQ.get() must not hang
+            for _, out_q in self.pairs:
+                out_q.put(err)
+            raise
         finally:
+            for ev in self.done:
+                ev.set()
             self.pool.close()
 
 
 class _Handle:
-    """What the reference's closeMultiProcPool expects of a worker process: join(), close()."""
+    """What the reference's closeMultiProcPool (gpsrecv.py:363-367) expects of a worker
+    process: join() returns once this worker's 'done' has been consumed, then close()."""
 
-    def __init__(self, thread):
-        self.thread = thread
+    def __init__(self, thread, done):
+        self.thread, self.done = thread, done
 
-    def join(self):
-        self.thread.join()
+    def join(self, timeout=None):
+        self.done.wait(timeout)
 
     def close(self):
         pass
@@ -126,8 +144,7 @@ def q_initMultiProcPool(poolNo, cfg=None, raw_u8=False, pool=None, make_queue=qu
     loop = WorkerLoop(pairs, cfg, raw_u8, pool)
     th = threading.Thread(target=loop.run, name='gpsmi-workers', daemon=True)
     th.start()
-    h = _Handle(th)
-    qpool = [(i, o, h) for i, o in pairs]
+    qpool = [(i, o, _Handle(th, loop.done[w])) for w, (i, o) in enumerate(pairs)]
     for wno, (in_q, _, _) in enumerate(qpool):
         in_q.put(('initPool', wno))
     for _, out_q, _ in qpool:
@@ -135,10 +152,12 @@ def q_initMultiProcPool(poolNo, cfg=None, raw_u8=False, pool=None, make_queue=qu
     return qpool, poolNo, [0] * poolNo
 
 
-def q_closeMultiProcPool(pool):             # gpsrecv.py:363-367
-    for in_q, _, _ in pool:
+def q_closeMultiProcPool(pool):             # gpsrecv.py:363-367, worker by worker as there
+    for in_q, _, handle in pool:
         in_q.put(('done', None))
-    pool[0][2].join()
+        handle.join()
+        handle.close()
+    pool[0][2].thread.join()                # (the one loop behind all of them has ended)
 
 
 def q_delPoolStreams(pool, poolNo, poolWorker, actSatSet, delSatSet):

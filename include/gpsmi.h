@@ -63,6 +63,33 @@ const char* gpsmi_version(void);
  * 4 offsetof(trk_out, code_phase); -1 otherwise.  Lets a binding verify its
  * own struct declarations before the first real call.                        */
 int gpsmi_abi_sizeof(int which);
+/* Kernel-variant selection and tuning thresholds, visible through the ABI (round 4: they used to
+ * be environment variables read inside gpsmi_*_create, invisible to a C caller; the variables
+ * still work, as the defaults of the options below when the ABI has not set them).
+ *   gpsmi_set_default(key, value)    process-wide, for handles created afterwards
+ *   gpsmi_clear_default(key)         back to the environment / built-in default
+ *   gpsmi_trk_set_option / gpsmi_trk_get_option   one live handle (further down)
+ * keys taken at create time:
+ *   "correlator"        1 (default): the matrix-pipe correlators where they exist (CS = 2048 with
+ *                       N_CYC = 32 / 16 / 8; CS = 16368 with N_CYC = 8); 0: the vector kernel
+ *                       everywhere (env GPSMI_STREAM_MFMA)
+ *   "codephase"         code_samples != 2048 only: 0 (default) native 16368-point LDS correlation
+ *                       / zero-padded 32768-point pair, 1 the exact time-domain kernel, 2 the
+ *                       32768-point pair at 16368 too (env GPSMI_DIRECT_CORR)
+ * keys a live tracking handle accepts as well (see DESIGN.md for the measurements behind them):
+ *   "corr_cg"           channels per code-phase-correlation workgroup in batches: 2, 4 (default), 6
+ *   "corr_small1/2"     jobs per launch up to which 1 / 2 channels per workgroup are taken (384, 1536)
+ *   "span_single_max"   (block, channel group) units up to which the span correlator runs one wave
+ *                       per span (80)
+ *   "stream_inline_max" bytes up to which gpsmi_trk_process_stream uploads in front of the step's
+ *                       own kernels (8 MiB)
+ *   "done_by_dispatch"  1 (default): a replay's epilogue waits on the correlator dispatch's own
+ *                       completion signal; 0: on an event record behind it
+ *   "corr_overlap"      1: gpsmi_trk_replay_run_async queues a batch's code-phase correlation on a
+ *                       second stream, so that it runs beside the previous batch's correlator
+ *                       (throughput mode; 0, the default, keeps every kernel alone on the chip) */
+int gpsmi_set_default(const char* key, long long value);
+int gpsmi_clear_default(const char* key);
 int gpsmi_device_count(int* n);
 int gpsmi_device_name(int device, char* buf, size_t len);
 
@@ -174,6 +201,13 @@ typedef struct gpsmi_trk_state {
                              /*   float64 product.  0 = FREQ is float32 and the */
                              /*   factor is float32(2*pi)*FREQ (NEP 50)         */
     float   df[GPSMI_MAX_DF];/* DF, oldest first                               */
+    /* decodeData's edge scan (gpslib.py:1394-1398, :1421-1436), carried on the device   */
+    int32_t edge_state;      /* 0: EDGES[0] not set yet; +1 / -1: prevSign; 2: prevSign */
+                             /*   is 0 (np.sign of an exact zero: no further edge until */
+                             /*   erasePrevData, as in the reference)                   */
+    float   prev_signal;     /* PREV_SIGNAL (:1434), the real part of the last dump      */
+    float   std_dev;         /* STD_DEV before the block: MIN_EDGE_AMP = 3*STD_DEV       */
+    int32_t reserved;        /* 0                                                        */
 } gpsmi_trk_state;
 
 /* Everything SatStream.process and its callers read back for one block.       */
@@ -195,7 +229,14 @@ typedef struct gpsmi_trk_out {
     float   freq, phase;                 /* FREQ, PHASE after the block         */
     int32_t phase_locked;                /* PHASE_LOCKED after the block        */
     int32_t nps;                         /* len(PREV_SAMPLES) after the block   */
-    int32_t reserved1;                   /* 0 (no implicit tail padding)        */
+    /* decodeData's edge list for this block (gpslib.py:1421-1436): bit i of the mask =  */
+    /* dump i appended an edge (MS_TIME before the block + i, ST + n0 of window i)       */
+    uint32_t edge_mask;                  /* dumps 0..31                         */
+    uint32_t edge_mask_hi;               /* bit 0: dump 32                      */
+    int32_t edge_sign0;                  /* the sign this block stored into EDGES[0]  */
+                                         /*   (first locked dump after a reset), else 0 */
+    int32_t ms_count;                    /* dumps counted into MS_TIME: n_dumps while  */
+                                         /*   PHASE_LOCKED was set before the block, else 0 */
 } gpsmi_trk_out;
 
 int gpsmi_trk_create(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk** out);
@@ -304,6 +345,17 @@ int gpsmi_trk_replay_states(gpsmi_trk* h, gpsmi_trk_state* states, size_t n);
  * event records is a barrier packet in the queue, ~5 us of pipeline bubble: a caller
  * that does not read gpsmi_trk_last_ms switches them off, a benchmark samples.   */
 int gpsmi_trk_set_timing(gpsmi_trk* h, int on);
+/* Options of one handle (keys: the table at gpsmi_set_default).  get reports what is in effect --
+ * for "correlator" / "codephase" the variant the handle actually runs.                  */
+int gpsmi_trk_set_option(gpsmi_trk* h, const char* key, long long value);
+int gpsmi_trk_get_option(gpsmi_trk* h, const char* key, long long* value);
+/* Introspection for tests (no GPU needed): grid size of the code-phase correlation launch over
+ * nblocks blocks x ngroups channel groups (negative: error), and the (block, group) workgroup wg
+ * of that launch serves -- block >= nblocks for a padding workgroup.  In batches the groups of a
+ * block are consecutive slots of ONE XCD (workgroup w runs on XCD w % 8): they share the block's
+ * rows through that XCD's L2 (csrc/gpsmi_wgmap.h).                                        */
+int gpsmi_trk_corr_grid(int nblocks, int ngroups);
+int gpsmi_trk_corr_wg_map(int nblocks, int ngroups, int wg, int* block, int* group);
 int gpsmi_trk_last_ms(gpsmi_trk* h, float* total_ms, float* correlator_ms);
 /* ... and from the start of the call's device work to the start of its correlator: the
  * code-phase correlation (cacodeCorr, gpslib.py:1315-1327) with everything in front of it.  */

@@ -120,3 +120,52 @@ def test_unpack_formula_matches_numpy_for_all_bytes():
     scl = np.float32(1.0) / np.float32(127.5)
     assert np.array_equal(ref.real, v.astype(np.float32) * scl - np.float32(1))
     assert np.array_equal(ref.imag, v[::-1].astype(np.float32) * scl - np.float32(1))
+
+
+@pytest.mark.parametrize('nblocks', [1, 7, 8, 9, 1024])
+@pytest.mark.parametrize('ng', [1, 3, 12])
+def test_codephase_correlation_workgroup_map(nblocks, ng):
+    """csrc/gpsmi_wgmap.h through gpsmi_trk_corr_grid / gpsmi_trk_corr_wg_map (the function the
+    host sizes the grid with and the kernel finds its unit with): every (block, group) is served
+    exactly once; in a batch (>= 8 blocks) all groups of a block sit on ONE XCD (workgroup w runs
+    on XCD w % 8) in consecutive slots, so the block's rows are fetched from HBM once and hit that
+    XCD's L2 for the other groups; fewer than 8 blocks launch exactly nblocks * ng workgroups.
+    (Round 3 inferred the mode from the grid size inside the kernel and silently lost the XCD
+    grouping for every block count that is a multiple of 8, the 1024-block batch included.)"""
+    from gpsmi import _lib
+    lib = _lib.load()
+    grid = lib.gpsmi_trk_corr_grid(nblocks, ng)
+    assert grid == (nblocks * ng if nblocks < 8 else -(-nblocks // 8) * 8 * ng)
+    seen, xcd_of, slots = set(), {}, {}
+    b, g = C.c_int(), C.c_int()
+    for wg in range(grid):
+        assert lib.gpsmi_trk_corr_wg_map(nblocks, ng, wg, C.byref(b), C.byref(g)) == 0
+        assert 0 <= g.value < ng
+        if b.value >= nblocks:
+            assert nblocks >= 8                        # padding workgroups only in batches
+            continue
+        assert (b.value, g.value) not in seen
+        seen.add((b.value, g.value))
+        xcd_of.setdefault(b.value, set()).add(wg % 8)
+        slots.setdefault(b.value, []).append(wg // 8)
+    assert seen == {(bb, gg) for bb in range(nblocks) for gg in range(ng)}
+    if nblocks >= 8:
+        for bb in range(nblocks):
+            assert len(xcd_of[bb]) == 1, (bb, xcd_of[bb])
+            assert slots[bb] == list(range(slots[bb][0], slots[bb][0] + ng))
+    assert lib.gpsmi_trk_corr_wg_map(nblocks, ng, grid, C.byref(b), C.byref(g)) == -1
+
+
+def test_options_are_part_of_the_abi():
+    """The kernel-variant / threshold switches are ABI calls (gpsmi_set_default for handles to
+    come, gpsmi_trk_set_option for a live one), not only environment variables."""
+    from gpsmi import _lib
+    lib = _lib.load()
+    assert lib.gpsmi_set_default(b'correlator', 0) == 0
+    assert lib.gpsmi_clear_default(b'correlator') == 0
+    assert lib.gpsmi_set_default(b'no_such_option', 1) == -1
+    assert b'no_such_option' in lib.gpsmi_last_error()
+    assert lib.gpsmi_set_default(None, 1) == -1
+    assert lib.gpsmi_trk_set_option(None, b'corr_cg', 4) == -1       # null handle
+    v = C.c_longlong()
+    assert lib.gpsmi_trk_get_option(None, b'corr_cg', C.byref(v)) == -1

@@ -319,28 +319,6 @@ def test_streams_and_streaming_errors_and_fallbacks(golden_default):
     got.close()
 
 
-def test_round1_matrix_correlator_agrees(closed_loop, monkeypatch):
-    """GPSMI_STREAM_MFMA=3: the round-1 correlator (v_mfma_f32_32x32x2_f32, four waves x 512
-    positions per workgroup, gpsmi_trk_stream_mfma.h) computes the same windows as the span
-    correlator; only the order of the float32 sums differs."""
-    from gpsmi.engine import TrkEngine, DeviceBuffer
-    _, outs, states, blocks = closed_loop
-    nb, nch = 8, outs.shape[1]
-    monkeypatch.setenv('GPSMI_STREAM_MFMA', '3')
-    eng = TrkEngine(max_ch=nch)
-    monkeypatch.delenv('GPSMI_STREAM_MFMA')
-    buf = DeviceBuffer(nb * blocks[0].nbytes)
-    for i in range(nb):
-        buf.upload(blocks[i], i * blocks[i].nbytes)
-    rep = eng.replay(buf.ptr, nb, states[:nb], outs['delay_used'][:nb])
-    buf.free()
-    eng.close()
-    for k in ('mx', 'delay', 'delay_used', 'n_dumps', 'nps', 'phase_locked'):
-        assert np.array_equal(rep[k], outs[:nb][k]), k
-    np.testing.assert_allclose(rep['dumps'], outs[:nb]['dumps'], rtol=2e-5, atol=2e-7)
-    np.testing.assert_allclose(rep['freq'], outs[:nb]['freq'], atol=1e-3)
-
-
 def test_pipelined_replay_runs_and_readbacks(closed_loop):
     """run_async / fetch_async / wait_prev: three runs in flight two at a time, every
     read-back equal to the blocking replay (two result slots, copy stream)."""
@@ -393,9 +371,9 @@ def test_async_batches_with_different_input_do_not_share_buffers(closed_loop, mo
     want = [ref_eng.replay(b.ptr, nb, table, forced).tobytes() for b in bufs]
     ref_eng.close()
     assert want[0] != want[1]
-    monkeypatch.setenv('GPSMI_DONE_BY_DISPATCH', done_by_dispatch)
     eng = TrkEngine(max_ch=nch)
-    monkeypatch.delenv('GPSMI_DONE_BY_DISPATCH')
+    eng.set_option('done_by_dispatch', int(done_by_dispatch))        # (an option of the ABI, gpsmi.h)
+    assert eng.get_option('done_by_dispatch') == int(done_by_dispatch)
     eng.replay_load(nb, table, forced)
     pins = [PinnedArray((nb, nch), OUT_DTYPE) for _ in range(2)]
     order = [0, 1, 1, 0, 1, 0, 0]
@@ -636,9 +614,13 @@ def test_vector_correlator_agrees_with_the_matrix_one(closed_loop, golden_defaul
     kernel does not apply: other block lengths, other code lengths) on the CS = 2048,
     N_CYC = 32 fixture: same reference parity, and against the default kernel only the
     order of the float32 sums differs."""
-    monkeypatch.setenv('GPSMI_STREAM_MFMA', '0')
-    r = _run_closed_loop(golden_default, 'default')
-    monkeypatch.delenv('GPSMI_STREAM_MFMA')
+    from gpsmi import engine as E
+    E.set_default('correlator', 0)                      # (gpsmi_set_default: for handles created from now on)
+    try:
+        r = _run_closed_loop(golden_default, 'default')
+    finally:
+        E.clear_default('correlator')
+    assert r[0].get_option('correlator') == 0
     r[0].close()
     _check_closed_loop(r[1], golden_default)
     outs = closed_loop[1]

@@ -11,8 +11,55 @@ from gpsmi.engine import Config
 from gpsmi.receiver import HostChannel, fit_code_phase
 
 
+_EDGE_CACHE = {}
+
+
+def edge_fields(g):
+    """What the device epilogue's edge scan reports for the fixture's dumps -- decodeData's rule
+    (gpslib.py:1394-1398, :1421-1436) on the float32 dumps, block after block per channel:
+    (edge_mask [nch, nb] as Python ints, edge_sign0, ms_count).  The kernel's scan is checked
+    against the reference's MS_TIME / edge counts on the GPU (tests/test_gpu_receiver.py)."""
+    key = id(g)
+    if key in _EDGE_CACHE:
+        return _EDGE_CACHE[key]
+    nch, nb = g['trk_delay'].shape
+    mask = [[0] * nb for _ in range(nch)]
+    sign0 = np.zeros((nch, nb), np.int32)
+    msc = np.zeros((nch, nb), np.int32)
+    for c in range(nch):
+        e0, prev_sign, prev_signal, std_dev, locked = 0, 0, np.float32(0), np.float32(0.005), False
+        for i in range(nb):
+            nd = int(g['trk_n_dumps'][c, i])
+            if locked:
+                thr = np.float32(3) * std_dev
+                for k in range(nd):
+                    re = np.float32(g['trk_dumps'][c, i, k].real)
+                    sgn = np.sign(re)
+                    if e0 == 0:
+                        e0 = prev_sign = sgn
+                        if sgn != 0 and sign0[c, i] == 0:
+                            sign0[c, i] = int(sgn)
+                    elif sgn != prev_sign and prev_sign * prev_signal > 0 and abs(re - prev_signal) > thr:
+                        mask[c][i] |= 1 << k
+                        prev_sign = sgn
+                    prev_signal = re
+                msc[c, i] = nd
+            std_dev = np.float32(g['trk_std_dev'][c, i])
+            locked = bool(g['trk_locked'][c, i])
+    _EDGE_CACHE[key] = (mask, sign0, msc)
+    return _EDGE_CACHE[key]
+
+
 def _record(g, c, i):
     r = np.zeros(1, dtype=OUT_DTYPE)[0]
+    mask, sign0, msc = edge_fields(g)
+    r['edge_mask'] = mask[c][i] & 0xFFFFFFFF
+    r['edge_mask_hi'] = mask[c][i] >> 32
+    r['edge_sign0'] = sign0[c, i]
+    r['ms_count'] = msc[c, i]
+    nps_prev = int(g['trk_nps'][c, i - 1]) if i else 0
+    n1 = nps_prev + int(g['trk_delay'][c, i])
+    r['first_len'] = n1 if n1 else 2048
     nd = int(g['trk_n_dumps'][c, i])
     d = g['trk_dumps'][c, i, :nd]
     r['n_dumps'] = nd

@@ -14,32 +14,43 @@ from test_receiver_host import _record
 
 
 class FixtureEngine:
-    """TrkEngine stand-in: process() returns block i of the fixture for every open channel."""
+    """TrkEngine stand-in with per-channel state: process() hands every open channel the fixture
+    block ITS position points at and advances all of them, as the real engine advances every
+    open channel's state; get_state / set_state carry the position (in `reserved`)."""
 
     def __init__(self, g, nch):
         self.g, self.nch = g, nch
         self.fix = {}                    # worker slot -> fixture channel
+        self.pos = {}                    # worker slot -> next fixture block
         self.block = 0
         self.calls = 0
 
     def open(self, ch, prn, freq, delay, stream=0):
         init = self.g['trk_init']
         self.fix[ch] = [c for c in range(len(init)) if int(init[c, 0]) == prn][0]
+        self.pos[ch] = self.block
 
     def close_channel(self, ch, stream=0):
         self.fix.pop(ch)
+        self.pos.pop(ch)
 
     def erase_prev(self, ch, stream=0):
         pass
 
     def get_state(self, ch, stream=0):
-        return np.zeros(1, dtype=STATE_DTYPE)[0]
+        st = np.zeros(1, dtype=STATE_DTYPE)[0]
+        st['reserved'] = self.pos.get(ch, 0)
+        return st
+
+    def set_state(self, ch, st, stream=0):
+        self.pos[ch] = int(st['reserved'])
 
     def process(self, data, want_out=True):
         from gpsmi._lib import OUT_DTYPE
         out = np.zeros(self.nch, dtype=OUT_DTYPE)
         for ch, c in self.fix.items():
-            out[ch] = _record(self.g, c, self.block)
+            out[ch] = _record(self.g, c, self.pos[ch])
+            self.pos[ch] += 1
         self.block += 1
         self.calls += 1
         return out
@@ -120,7 +131,16 @@ def test_messages_and_answers_have_the_reference_shapes(golden_default):
     i1.put(('initInst', (int(sv1), float(f1), int(d1))))
     assert o1.get(timeout=5) == int(sv1)
     i1.put(('runInst', (np.zeros(65536, np.complex64), np.int64(7 * 65536))))
-    assert o1.get(timeout=5)[1] == int(sv1)
+    late_first = o1.get(timeout=5)
+    assert late_first[1] == int(sv1)
+    # the other worker's message for the SAME block arrives late: its channel must not have been
+    # advanced by the partial burst (and worker 1's not again by this one)
+    i0.put(('runInst', (np.zeros(65536, np.complex64), np.int64(7 * 65536))))
+    late = o0.get(timeout=5)
+    assert late[1] == int(sv)
+    assert eng.pos == {0: 2, 1: 2}                    # each channel saw two blocks, once each
+    assert late[3] == float(g['trk_code_phase'][eng.fix[0], 1])
+    assert late_first[3] == float(g['trk_code_phase'][eng.fix[1], 1])
     i0.put(('delInst', None))
     assert o0.get(timeout=5) is True
     for q in (i0, i1):

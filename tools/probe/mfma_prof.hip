@@ -8,6 +8,9 @@
 //   tools/probe/mfma_prof 1024 x      (blocks; any second argument adds the 8-block runs)
 #define GPSMI_MF_PROF 1
 #include "../../gps-sdr-receiver_amd/csrc/gpsmi_trk.hip"
+#pragma clang fp contract(fast)
+#include "round1_stream_mfma.h"      // the round-1 correlator, retired from the library in round 4
+#pragma clang fp contract(off)
 
 #include <algorithm>
 #include <cmath>

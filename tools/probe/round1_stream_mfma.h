@@ -58,7 +58,7 @@ constexpr int kMfRowDw = 2 * kMfTile + 2; // dwords per tile row: lane = row rea
 constexpr int kMfTileFloats = 32 * kMfRowDw;
 constexpr int kMfCodePitch = kMfTile + 4; // floats per replica row: b128 reads conflict-free
 constexpr int kMfReseed = 8;              // tiles between exact phasors
-constexpr int kMfRsrcFlags = 0x00020000;  // raw buffer descriptor, 32-bit data format (gfx9)
+constexpr int kMfRsrcFlags = kRsrcFlags;
 
 typedef float mf16 __attribute__((ext_vector_type(16)));
 typedef float mf2 __attribute__((ext_vector_type(2)));

@@ -8,6 +8,9 @@
 // With -DGPSMI_SPAN_STAMPS (-o tools/probe/span_stamps): the checks, then the 100 MHz phase stamps of
 // one launch of the batch form (where a unit's time goes besides its tile loop) and nothing else.
 #include "../../gps-sdr-receiver_amd/csrc/gpsmi_trk.hip"
+#pragma clang fp contract(fast)
+#include "round1_stream_mfma.h"      // the round-1 correlator, retired from the library in round 4
+#pragma clang fp contract(off)
 
 #include <algorithm>
 #include <cmath>
