@@ -340,6 +340,7 @@ __device__ __forceinline__ void epilogue_job(const gpsmi_trk_state& si, gpsmi_tr
         o.edge_mask_hi = (uint32_t)(edge_mask >> 32);
         o.edge_sign0 = edge_sign0;
         o.ms_count = ms_count;
+        o.reserved1 = 0;
     }
 }
 

@@ -53,7 +53,7 @@ OUT_DTYPE = np.dtype([
     ('phase_shift', np.float32), ('freq', np.float32), ('phase', np.float32),
     ('phase_locked', np.int32), ('nps', np.int32),
     ('edge_mask', np.uint32), ('edge_mask_hi', np.uint32), ('edge_sign0', np.int32),
-    ('ms_count', np.int32)],
+    ('ms_count', np.int32), ('reserved1', np.int32)],
     align=True)
 
 EXPORTS = [

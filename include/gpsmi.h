@@ -237,6 +237,7 @@ typedef struct gpsmi_trk_out {
                                          /*   (first locked dump after a reset), else 0 */
     int32_t ms_count;                    /* dumps counted into MS_TIME: n_dumps while  */
                                          /*   PHASE_LOCKED was set before the block, else 0 */
+    int32_t reserved1;                   /* 0 (no implicit tail padding)        */
 } gpsmi_trk_out;
 
 int gpsmi_trk_create(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk** out);

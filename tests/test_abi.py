@@ -37,6 +37,11 @@ def test_struct_layouts():
     assert lib.gpsmi_abi_sizeof(4) == _lib.OUT_DTYPE.fields['code_phase'][1]
     assert lib.gpsmi_abi_sizeof(99) == -1
     assert b'gfx950' in lib.gpsmi_version()
+    # no implicit padding anywhere in the records that cross the ABI: every byte is a field the
+    # kernels write, so two runs can be compared bytewise (a padded tail would carry garbage)
+    for dt in (_lib.OUT_DTYPE, _lib.STATE_DTYPE, _lib.PEAK_DTYPE):
+        covered = sum(dt.fields[n][0].itemsize for n in dt.names)
+        assert covered == dt.itemsize, (dt.names, covered, dt.itemsize)
 
 
 def test_argument_errors_do_not_need_a_gpu():
