@@ -392,6 +392,57 @@ def measure_streamed(E, local, raw_blocks, chans, Rs=(1, 8, 32), steps=48):
             'runs': res}
 
 
+def measure_dropin(E, local, raw, n_blocks):
+    """The path a user of the reference calls: ``pipeline.Receiver.feed(block)`` per 32-ms block --
+    gpsrecv.processData's loop (gpsrecv.py:466-519): cold sweep over the first blocks
+    (sweepAllSats, getNewSats, initPoolStreams), then satCalc + hand-off per block, a pickled
+    datagram once a second -- fed from HOST memory block by block (complex64 as streamData hands
+    them on, and the recorder's raw uint16), 12 channels (MAX_SAT = 12), everything inside the
+    timed loop: the host copy into page-locked memory, the upload, the kernels, the record
+    read-back, the host bookkeeping and the pickling.  `tracking_only` starts the clock at the
+    first tracking block (the cold sweep's five blocks are synchronous searches)."""
+    import pickle
+    from gpsmi.pipeline import Receiver
+    from gpsmi.synth import raw_to_c64
+    out = []
+    for raw_u8 in (False, True):
+        blocks = [np.ascontiguousarray(raw[i]) if raw_u8 else raw_to_c64(raw[i]) for i in range(n_blocks)]
+        best = None
+        for rep in range(2):
+            rx = Receiver(E.Config(device=local, max_sat=N_CH), raw_u8=raw_u8)
+            n_dg, t_trk = 0, None
+            E.sync(local)
+            t0 = time.perf_counter()
+            for i, b in enumerate(blocks):
+                if t_trk is None and not rx.sweep_all_freq:
+                    rx.drain()
+                    t_trk, i_trk = time.perf_counter(), i
+                if rx.feed(b) is not None:
+                    n_dg += 1
+            rx.drain()
+            t1 = time.perf_counter()
+            n_ch = len(rx.act_sat_set)
+            last = pickle.loads(rx.result_list[-1]) if rx.result_list else None
+            rx.close()
+            r = {'input': 'raw uint16 (Q<<8|I), 2 B/sample' if raw_u8 else 'complex64, 8 B/sample',
+                 'blocks': n_blocks, 'channels': n_ch, 'datagrams': n_dg,
+                 'us_per_block': round((t1 - t0) / n_blocks * 1e6, 2),
+                 'msamples_per_s': round(n_blocks * NGPS / (t1 - t0) / 1e6, 1),
+                 'x_realtime': round(n_blocks * NGPS / (t1 - t0) / 2.048e6, 1),
+                 'tracking_only': {
+                     'blocks': n_blocks - i_trk,
+                     'us_per_block': round((t1 - t_trk) / (n_blocks - i_trk) * 1e6, 2),
+                     'x_realtime': round((n_blocks - i_trk) * NGPS / (t1 - t_trk) / 2.048e6, 1)},
+                 'satellites_in_last_datagram': len(last[2]) if last else 0}
+            if best is None or r['us_per_block'] < best['us_per_block']:
+                best = r
+        out.append(best)
+    return {'what': 'pipeline.Receiver.feed per 32-ms block from host memory: processData\'s loop '
+                    '(cold sweep, channel selection, satCalc, hand-off datagrams), host work and PCIe '
+                    'inside the timed loop; better of two runs',
+            'runs': out}
+
+
 def measure_multi(E, sharding, dist, torch, lib, comm, rank, world, local, a, nb, trk_base, d_iq,
                   chans_all, states, cl_out, gather_peaks, cells, dt_mine, acq_ms, by_channel):
     """What an N > 1 run reports besides the headline (all ranks call this, after the timed
@@ -493,6 +544,8 @@ def main():
                          'steady clocks (see the module docstring); 0 = none')
     ap.add_argument('--blocks', type=int, default=1024)
     ap.add_argument('--cpu-blocks', type=int, default=192)
+    ap.add_argument('--dropin-blocks', type=int, default=640,
+                    help='blocks the drop-in leg feeds through pipeline.Receiver.feed (20 s of signal)')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the configs[3] / configs[4] legs')
     ap.add_argument('--shard', choices=('time', 'channels'), default='time',
@@ -787,6 +840,9 @@ def main():
             extra.append(measure_u8(E, local, d_raw, nb, chans, states, cl_out['delay_used'], cl_out))
             extra.append(measure_cfg5(E, local))
             extra.append(measure_streamed(E, local, raw[N_ACQ_BLOCKS:N_ACQ_BLOCKS + 96], chans))
+    dropin = None
+    if rank == 0 and world == 1 and not a.no_extra:
+        dropin = measure_dropin(E, local, raw, min(nb, a.dropin_blocks) + N_ACQ_BLOCKS)
 
     if rank == 0:
         samples = nb * NGPS
@@ -868,6 +924,7 @@ def main():
                                 'bytewise equal to its solo closed loop (tests/test_gpu_trk.py)',
             },
             'configs': extra,
+            'dropin': dropin,
             'multi_gpu': multi,
             'checks': checks,
             'device': dev_name,

@@ -32,6 +32,10 @@ int fail(int code, const char* fmt, ...);
 // Keys: see the table in gpsmi_core.hip.  -> false for an unknown key.
 bool default_opt(const char* key, long long* value, long long fallback);
 
+// Is [p, p + bytes) inside a block handed out by gpsmi_host_alloc (and not freed since)?  -> the
+// address a kernel reaches it at.
+bool host_alloc_lookup(const void* p, size_t bytes, void** dev);
+
 // exp(-2 pi i k / 2048) computed in double, rounded once.
 void make_twiddles(std::vector<float2>& tw);
 

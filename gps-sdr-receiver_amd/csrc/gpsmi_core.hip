@@ -39,6 +39,8 @@ static OptDef g_opts[] = {
     {"stream_inline_max", "GPSMI_STREAM_INLINE_MAX", false, 0},
     {"done_by_dispatch", "GPSMI_DONE_BY_DISPATCH", false, 0},
     {"corr_overlap", "GPSMI_CORR_OVERLAP", false, 0},
+    {"stream_thread", "GPSMI_STREAM_THREAD", false, 0},
+    {"stream_depth", "GPSMI_STREAM_DEPTH", false, 0},
     {"debug_flags", "GPSMI_DEBUG_FLAGS", false, 0},
 };
 static std::mutex g_opts_mutex;
@@ -65,6 +67,22 @@ bool default_opt(const char* key, long long* value, long long fallback) {
         if (const char* e = getenv(o->env)) *value = atoll(e);
     }
     return true;
+}
+
+// the page-locked blocks gpsmi_host_alloc has handed out
+struct HostAlloc { char* base; size_t bytes; char* dev; };
+static std::vector<HostAlloc> g_host_allocs;
+static std::mutex g_host_mutex;
+
+bool host_alloc_lookup(const void* p, size_t bytes, void** dev) {
+    std::lock_guard<std::mutex> lock(g_host_mutex);
+    const char* c = static_cast<const char*>(p);
+    for (const auto& a : g_host_allocs)
+        if (c >= a.base && c + bytes <= a.base + a.bytes) {
+            *dev = a.dev + (c - a.base);
+            return true;
+        }
+    return false;
 }
 
 void make_twiddles(std::vector<float2>& tw) {
@@ -176,11 +194,26 @@ int gpsmi_dev_download(int device, void* host, const void* dptr, size_t bytes) {
 int gpsmi_host_alloc(size_t bytes, void** hptr) {
     GPSMI_REQUIRE(hptr && bytes > 0, "null pointer or zero size");
     GPSMI_HIP(hipHostMalloc(hptr, bytes, hipHostMallocDefault));
+    void* dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, *hptr, 0) == hipSuccess && dev) {
+        std::lock_guard<std::mutex> lock(g_host_mutex);
+        g_host_allocs.push_back({static_cast<char*>(*hptr), bytes, static_cast<char*>(dev)});
+    } else {
+        (void)hipGetLastError();
+    }
     return GPSMI_OK;
 }
 
 int gpsmi_host_free(void* hptr) {
     if (!hptr) return GPSMI_OK;
+    {
+        std::lock_guard<std::mutex> lock(g_host_mutex);
+        for (size_t i = 0; i < g_host_allocs.size(); ++i)
+            if (g_host_allocs[i].base == hptr) {
+                g_host_allocs.erase(g_host_allocs.begin() + i);
+                break;
+            }
+    }
     GPSMI_HIP(hipHostFree(hptr));
     return GPSMI_OK;
 }

@@ -25,9 +25,14 @@
 //
 // Loop-carried state lives in device memory; the closed loop needs no host
 // round trip between blocks.
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include <hip/hip_ext.h>
@@ -545,6 +550,29 @@ struct gpsmi_trk {
     float2* d_RSp = nullptr;
     bool span8 = false;              // the matrix-pipe correlator for CS = 16368, N_CYC = 8 (gpsmi_trk_span8.h)
     TrkParams P;
+    // gpsmi_trk_process_stream's submission thread (option "stream_thread", default on): the four
+    // launches and the event record of a streamed step cost ~25 us of runtime calls on the host --
+    // as long as the step runs on the GPU -- so they are made by a thread of the handle's own while
+    // the caller prepares its next block.  Every other entry point first waits for this thread to
+    // have nothing queued (trk_quiesce), so at any time only one thread works on the handle.
+    struct StreamJob { const void* iq; size_t n; gpsmi_trk_out* out; };
+    struct StreamWorker {
+        std::thread th;
+        std::mutex m;
+        std::condition_variable cv_job, cv_done;
+        std::deque<StreamJob> q;
+        bool stop = false;
+        long long submitted = 0;     // jobs handed over
+        long long cleared = 0;       // jobs whose step before last has been seen complete (the caller may go on)
+        long long finished = 0;      // jobs fully enqueued on the device
+        int err = 0;
+        char errmsg[512] = "";
+    };
+    StreamWorker* worker = nullptr;
+    int stream_thread = 1;
+    int stream_depth = 2;            // calls a streamed step's buffers stay in use: 2 (gpsmi.h) or 3
+    long long stat_wait_ns = 0, stat_launch_ns = 0, stat_steps = 0;   // streamed steps: host time waiting for the
+                                                                      // step before last / making the runtime calls
 };
 
 constexpr int kSpanUnitsMax = 256;   // (block, channel group) units the single-block span form can serve (records)
@@ -762,7 +790,7 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
 
 namespace gpsmi {
 HandleSync acq_sync(gpsmi_acq* h);
-HandleSync trk_sync(gpsmi_trk* h) { return HandleSync{h->stream, h->order, h->cfg.device, h->main_tail}; }
+HandleSync trk_sync(gpsmi_trk* h);
 }  // namespace gpsmi
 
 // kernel times of a finished launch into last_*_ms
@@ -810,6 +838,95 @@ static int trk_pull_state(gpsmi_trk* h) {
     GPSMI_HIP(hipStreamSynchronize(h->stream));
     return GPSMI_OK;
 }
+
+// Is [p, p + bytes) page-locked host memory a kernel may address?  -> its device pointer.
+// (memory from gpsmi_host_alloc is known without asking the runtime: hipPointerGetAttributes costs
+// ~2 us a call, twice per step)
+static bool trk_pinned_dev(gpsmi_trk* h, const void* p, size_t bytes, void** dev) {
+    (void)h;
+    if (bytes % 16 != 0 || ((uintptr_t)p & 15) != 0) return false;
+    if (host_alloc_lookup(p, bytes, dev)) return true;
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();            // an unregistered pointer is not an error here
+        return false;
+    }
+    if (at.type != hipMemoryTypeHost || at.devicePointer == nullptr) return false;
+    hipPointerAttribute_t at_end{};
+    const char* last = static_cast<const char*>(p) + bytes - 1;
+    if (hipPointerGetAttributes(&at_end, last) != hipSuccess || at_end.type != hipMemoryTypeHost) {
+        (void)hipGetLastError();
+        return false;
+    }
+    *dev = at.devicePointer;
+    return true;
+}
+
+static int trk_stream_step(gpsmi_trk* h, const void* iq, size_t n, gpsmi_trk_out* out,
+                           void (*cleared)(gpsmi_trk*) = nullptr);
+
+static void trk_worker_cleared(gpsmi_trk* h) {
+    gpsmi_trk::StreamWorker& w = *h->worker;
+    {
+        std::lock_guard<std::mutex> lock(w.m);
+        w.cleared = w.finished + 1;             // (the job in hand)
+    }
+    w.cv_done.notify_all();
+}
+
+static void trk_worker_main(gpsmi_trk* h) {
+    gpsmi_trk::StreamWorker& w = *h->worker;
+    (void)hipSetDevice(h->cfg.device);
+    for (;;) {
+        gpsmi_trk::StreamJob job;
+        {
+            std::unique_lock<std::mutex> lock(w.m);
+            w.cv_job.wait(lock, [&] { return w.stop || !w.q.empty(); });
+            if (w.q.empty()) return;            // (stop, and nothing left to enqueue)
+            job = w.q.front();
+        }
+        int rc = w.err ? w.err : trk_stream_step(h, job.iq, job.n, job.out, trk_worker_cleared);
+        {
+            std::lock_guard<std::mutex> lock(w.m);
+            if (rc && !w.err) {                 // the first failure is kept for the caller
+                w.err = rc;
+                snprintf(w.errmsg, sizeof(w.errmsg), "%s", last_error_buf());
+            }
+            w.q.pop_front();
+            w.finished += 1;
+            if (w.cleared < w.finished) w.cleared = w.finished;
+        }
+        w.cv_done.notify_all();
+    }
+}
+
+// Nothing is queued on the submission thread and it is idle: from here on the calling thread is the
+// only one working on the handle.  A failure of a streamed step surfaces here (once).
+static int trk_quiesce(gpsmi_trk* h) {
+    if (!h || !h->worker) return GPSMI_OK;
+    gpsmi_trk::StreamWorker& w = *h->worker;
+    std::unique_lock<std::mutex> lock(w.m);
+    w.cv_done.wait(lock, [&] { return w.finished == w.submitted; });
+    if (w.err) {
+        const int rc = w.err;
+        w.err = 0;
+        return fail(rc, "a streamed step failed: %s", w.errmsg);
+    }
+    return GPSMI_OK;
+}
+
+#define GPSMI_QUIESCE(h)                 \
+    do {                                 \
+        int rc_q__ = trk_quiesce(h);     \
+        if (rc_q__) return rc_q__;       \
+    } while (0)
+
+namespace gpsmi {
+HandleSync trk_sync(gpsmi_trk* h) {
+    (void)trk_quiesce(h);                  // (a streamed step still being enqueued belongs in front)
+    return HandleSync{h->stream, h->order, h->cfg.device, h->main_tail};
+}
+}  // namespace gpsmi
 
 extern "C" {
 
@@ -934,7 +1051,8 @@ static int trk_build(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk* h) {
     P.flags = (int)v;
     const struct { const char* key; long long fallback; } tun[] = {
         {"corr_cg", h->corr_cg}, {"span_single_max", h->span_single_max}, {"stream_inline_max", (long long)h->stream_inline_max},
-        {"done_by_dispatch", h->done_by_dispatch}, {"corr_overlap", h->corr_overlap}};
+        {"done_by_dispatch", h->done_by_dispatch}, {"corr_overlap", h->corr_overlap},
+        {"stream_thread", h->stream_thread}, {"stream_depth", h->stream_depth}};
     for (const auto& t : tun) {
         default_opt(t.key, &v, t.fallback);
         if (v != t.fallback) (void)gpsmi_trk_set_option(h, t.key, v);   // (an out-of-range default is ignored)
@@ -950,6 +1068,17 @@ extern "C" {
 
 int gpsmi_trk_destroy(gpsmi_trk* h) {
     if (!h) return GPSMI_OK;
+    if (h->worker) {
+        (void)trk_quiesce(h);
+        {
+            std::lock_guard<std::mutex> lock(h->worker->m);
+            h->worker->stop = true;
+        }
+        h->worker->cv_job.notify_all();
+        h->worker->th.join();
+        delete h->worker;
+        h->worker = nullptr;
+    }
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
@@ -989,6 +1118,7 @@ int gpsmi_trk_destroy(gpsmi_trk* h) {
 int gpsmi_trk_set_replica(gpsmi_trk* h, int prn, const float* replica, const float* spectrum) {
     GPSMI_REQUIRE(h && replica && (spectrum || h->general), "null argument");
     GPSMI_REQUIRE(prn >= 1 && prn <= GPSMI_MAX_PRN, "prn out of range 1..37");
+    GPSMI_QUIESCE(h);
     GPSMI_HIP(hipSetDevice(h->cfg.device));
     const size_t cs = h->cfg.code_samples;
     GPSMI_HIP(hipMemcpy(h->d_code + (size_t)prn * cs, replica, cs * sizeof(float),
@@ -1022,6 +1152,7 @@ int gpsmi_trk_set_replica(gpsmi_trk* h, int prn, const float* replica, const flo
 
 int gpsmi_trk_open(gpsmi_trk* h, int ch, int prn, float freq_hz, int delay) {
     GPSMI_REQUIRE(h, "null handle");
+    GPSMI_QUIESCE(h);
     GPSMI_REQUIRE(ch >= 0 && ch < h->rows(), "channel out of range");
     GPSMI_REQUIRE(prn >= 1 && prn <= GPSMI_MAX_PRN, "prn out of range 1..37");
     GPSMI_REQUIRE(delay >= 0 && delay < h->cfg.code_samples, "delay out of range");
@@ -1041,6 +1172,7 @@ int gpsmi_trk_open(gpsmi_trk* h, int ch, int prn, float freq_hz, int delay) {
 
 int gpsmi_trk_close(gpsmi_trk* h, int ch) {
     GPSMI_REQUIRE(h, "null handle");
+    GPSMI_QUIESCE(h);
     GPSMI_REQUIRE(ch >= 0 && ch < h->rows(), "channel out of range");
     GPSMI_HIP(hipSetDevice(h->cfg.device));
     int rc = trk_pull_state(h);
@@ -1053,6 +1185,7 @@ int gpsmi_trk_close(gpsmi_trk* h, int ch) {
 
 int gpsmi_trk_get_state(gpsmi_trk* h, int ch, gpsmi_trk_state* st) {
     GPSMI_REQUIRE(h && st, "null argument");
+    GPSMI_QUIESCE(h);
     GPSMI_REQUIRE(ch >= 0 && ch < h->rows(), "channel out of range");
     GPSMI_HIP(hipSetDevice(h->cfg.device));
     int rc = trk_pull_state(h);
@@ -1063,6 +1196,7 @@ int gpsmi_trk_get_state(gpsmi_trk* h, int ch, gpsmi_trk_state* st) {
 
 int gpsmi_trk_set_state(gpsmi_trk* h, int ch, const gpsmi_trk_state* st) {
     GPSMI_REQUIRE(h && st, "null argument");
+    GPSMI_QUIESCE(h);
     GPSMI_REQUIRE(ch >= 0 && ch < h->rows(), "channel out of range");
     GPSMI_REQUIRE(st->prn >= 0 && st->prn <= GPSMI_MAX_PRN, "prn out of range");
     GPSMI_REQUIRE(st->delay >= 0 && st->delay < h->cfg.code_samples, "delay out of range");
@@ -1081,6 +1215,7 @@ int gpsmi_trk_set_state(gpsmi_trk* h, int ch, const gpsmi_trk_state* st) {
 
 int gpsmi_trk_erase_prev(gpsmi_trk* h, int ch) {
     GPSMI_REQUIRE(h, "null handle");
+    GPSMI_QUIESCE(h);
     GPSMI_REQUIRE(ch >= 0 && ch < h->rows(), "channel out of range");
     GPSMI_HIP(hipSetDevice(h->cfg.device));
     int rc = trk_pull_state(h);
@@ -1094,6 +1229,7 @@ int gpsmi_trk_erase_prev(gpsmi_trk* h, int ch) {
 
 int gpsmi_trk_process_dev(gpsmi_trk* h, const void* d_iq, size_t n, gpsmi_trk_out* out) {
     GPSMI_REQUIRE(h && d_iq, "null argument");
+    GPSMI_QUIESCE(h);
     GPSMI_REQUIRE(n == (size_t)h->n_streams * h->cfg.n_cyc * h->cfg.code_samples,
                   "input must hold one block of NGPS samples per stream");
     GPSMI_HIP(hipSetDevice(h->cfg.device));
@@ -1128,6 +1264,7 @@ int gpsmi_trk_process_dev(gpsmi_trk* h, const void* d_iq, size_t n, gpsmi_trk_ou
 
 int gpsmi_trk_process(gpsmi_trk* h, const float* iq, size_t n, gpsmi_trk_out* out) {
     GPSMI_REQUIRE(h && iq && out, "null argument");
+    GPSMI_QUIESCE(h);
     GPSMI_REQUIRE(n == (size_t)h->n_streams * h->cfg.n_cyc * h->cfg.code_samples,
                   "input must hold one block of NGPS samples per stream");
     GPSMI_HIP(hipSetDevice(h->cfg.device));
@@ -1137,10 +1274,11 @@ int gpsmi_trk_process(gpsmi_trk* h, const float* iq, size_t n, gpsmi_trk_out* ou
     return gpsmi_trk_process_dev(h, h->d_block, n, out);
 }
 
-int gpsmi_trk_process_stream(gpsmi_trk* h, const void* iq, size_t n, gpsmi_trk_out* out) {
-    GPSMI_REQUIRE(h && iq, "null argument");
-    GPSMI_REQUIRE(n == (size_t)h->n_streams * h->cfg.n_cyc * h->cfg.code_samples,
-                  "input must hold one block of NGPS samples per stream");
+// One streamed step: everything gpsmi_trk_process_stream promises, made by whichever thread works
+// on the handle (the caller, or the handle's submission thread).  `cleared`, if given, is told as soon
+// as the step before last is known to be complete.
+static int trk_stream_step(gpsmi_trk* h, const void* iq, size_t n, gpsmi_trk_out* out,
+                           void (*cleared)(gpsmi_trk*)) {
     GPSMI_HIP(hipSetDevice(h->cfg.device));
     const size_t bytes = n * (h->iq_fmt == GPSMI_IQ_U8 ? 2 : sizeof(float2));
     if (!h->up_stream) {
@@ -1175,26 +1313,22 @@ int gpsmi_trk_process_stream(gpsmi_trk* h, const void* iq, size_t n, gpsmi_trk_o
     // back-pressure: the step of the call before last has finished when this call returns (its iq may
     // be rewritten, its out is filled) -- the contract of gpsmi.h; the host therefore runs at most two
     // steps ahead of the device, which keeps one whole step queued behind the one that is running
+    const auto t_w0 = std::chrono::steady_clock::now();
     if (h->in_pending[s]) {
         GPSMI_HIP(hipEventSynchronize(h->in_done[s]));
         h->in_pending[s] = false;
     }
+    const auto t_w1 = std::chrono::steady_clock::now();
+    h->stat_wait_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(t_w1 - t_w0).count();
+    if (cleared) cleared(h);
     // page-locked memory is read by a kernel (see stage_copy_kernel); anything else -- pageable
     // memory would fault under a kernel -- goes through the runtime's copy
-    bool pinned = false;
-    hipPointerAttribute_t at{};
-    if (bytes % 16 == 0 && ((uintptr_t)iq & 15) == 0) {
-        if (hipPointerGetAttributes(&at, iq) == hipSuccess)
-            pinned = at.type == hipMemoryTypeHost && at.devicePointer != nullptr;
-        else
-            (void)hipGetLastError();        // an unregistered pointer is not an error here
-        if (pinned) {
-            hipPointerAttribute_t at_end{};
-            const char* last = static_cast<const char*>(iq) + bytes - 1;
-            pinned = hipPointerGetAttributes(&at_end, last) == hipSuccess && at_end.type == hipMemoryTypeHost;
-            if (!pinned) (void)hipGetLastError();
-        }
-    }
+    void* iq_dev = nullptr;
+    const bool pinned = trk_pinned_dev(h, iq, bytes, &iq_dev);
+    // the records of a step go straight into a page-locked `out` (the two kernels that fill a record
+    // store over PCIe: 376 bytes per channel) instead of through d_out and a copy command behind them
+    void* out_dev = nullptr;
+    const bool out_direct = out && trk_pinned_dev(h, out, (size_t)h->rows() * sizeof(gpsmi_trk_out), &out_dev);
     // Up to 8 MiB per step (measured: one receiver's 128 KiB to 64 receivers' 8 MiB of raw samples)
     // the block goes up IN FRONT of its own kernels on the main stream: the two event packets that
     // order an upload stream against the main one cost ~7 us per step, and a copy kernel beside the
@@ -1209,7 +1343,7 @@ int gpsmi_trk_process_stream(gpsmi_trk* h, const void* iq, size_t n, gpsmi_trk_o
         const size_t n16 = bytes / 16;
         const unsigned grid = (unsigned)((n16 + 255) / 256 < 512 ? (n16 + 255) / 256 : 512);
         hipLaunchKernelGGL(stage_copy_kernel, dim3(grid), dim3(256), 0, us,
-                           static_cast<stage_u4*>(h->d_stage[s]), static_cast<const stage_u4*>(at.devicePointer), n16);
+                           static_cast<stage_u4*>(h->d_stage[s]), static_cast<const stage_u4*>(iq_dev), n16);
     } else {
         GPSMI_HIP(hipMemcpyAsync(h->d_stage[s], iq, bytes, hipMemcpyHostToDevice, us));
     }
@@ -1221,7 +1355,10 @@ int gpsmi_trk_process_stream(gpsmi_trk* h, const void* iq, size_t n, gpsmi_trk_o
     h->cur = 0;
     const bool timing = h->timing;
     h->timing = false;                      // (no kernel-timing events in a streaming loop)
+    gpsmi_trk_out* const d_out_keep = sl.d_out;
+    if (out_direct) sl.d_out = static_cast<gpsmi_trk_out*>(out_dev);
     rc = trk_launch(h, sl, h->d_stage[s], h->d_state, h->d_state, nullptr, h->rows(), h->max_ch);
+    sl.d_out = d_out_keep;
     h->timing = timing;
     if (rc) return rc;
     if (!in_line) {
@@ -1230,17 +1367,54 @@ int gpsmi_trk_process_stream(gpsmi_trk* h, const void* iq, size_t n, gpsmi_trk_o
     } else {
         h->stage_used[s] = false;           // (same stream: the next writer of this block queues behind its readers)
     }
-    if (out)
+    if (out && !out_direct)
         GPSMI_HIP(hipMemcpyAsync(out, sl.d_out, h->rows() * sizeof(gpsmi_trk_out),
                                  hipMemcpyDeviceToHost, h->stream));
     GPSMI_HIP(hipEventRecord(h->in_done[s], h->stream));
     h->in_pending[s] = true;
+    h->stat_launch_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_w1).count();
+    h->stat_steps += 1;
+    return GPSMI_OK;
+}
+
+
+int gpsmi_trk_process_stream(gpsmi_trk* h, const void* iq, size_t n, gpsmi_trk_out* out) {
+    GPSMI_REQUIRE(h && iq, "null argument");
+    GPSMI_REQUIRE(n == (size_t)h->n_streams * h->cfg.n_cyc * h->cfg.code_samples,
+                  "input must hold one block of NGPS samples per stream");
+    if (!h->stream_thread) {
+        GPSMI_QUIESCE(h);
+        return trk_stream_step(h, iq, n, out);
+    }
+    if (!h->worker) {
+        h->worker = new (std::nothrow) gpsmi_trk::StreamWorker();
+        if (!h->worker) return fail(GPSMI_E_NOMEM, "out of host memory");
+        h->worker->th = std::thread(trk_worker_main, h);
+    }
+    gpsmi_trk::StreamWorker& w = *h->worker;
+    std::unique_lock<std::mutex> lock(w.m);
+    if (w.err) {                                // an earlier step failed: report it instead of queueing more
+        w.cv_done.wait(lock, [&] { return w.finished == w.submitted; });
+        const int rc = w.err;
+        w.err = 0;
+        return fail(rc, "a streamed step failed: %s", w.errmsg);
+    }
+    w.q.push_back({iq, n, out});
+    const long long k = ++w.submitted;          // this job's ordinal, from 1
+    w.cv_job.notify_one();
+    // the contract of gpsmi.h: return once the step of the call before last is complete -- the
+    // submission thread says so when it has waited for that step on its way into this one
+    // ("stream_depth" = 3: one step more -- the call returns when the step three calls back is
+    // complete, so the caller can hand over its next block while this one is still being enqueued)
+    const long long need = k - (h->stream_depth - 2);
+    w.cv_done.wait(lock, [&] { return w.cleared >= need; });
     return GPSMI_OK;
 }
 
 int gpsmi_trk_replay_load(gpsmi_trk* h, int nb, const gpsmi_trk_state* table,
                           const int32_t* delay_used) {
     GPSMI_REQUIRE(h && table, "null argument");
+    GPSMI_QUIESCE(h);
     GPSMI_REQUIRE(nb >= 1, "block count must be >= 1");
     if (h->n_streams != 1) return fail(GPSMI_E_STATE, "replay takes a handle with one stream");
     GPSMI_HIP(hipSetDevice(h->cfg.device));
@@ -1281,6 +1455,7 @@ int gpsmi_trk_replay_load(gpsmi_trk* h, int nb, const gpsmi_trk_state* table,
 
 int gpsmi_trk_replay_run_async(gpsmi_trk* h, const void* d_iq, int nb) {
     GPSMI_REQUIRE(h && d_iq, "null argument");
+    GPSMI_QUIESCE(h);
     if (nb != h->replay_nb || nb < 1)
         return fail(GPSMI_E_STATE, "replay_run(nb=%d) without a matching replay_load (nb=%d)", nb,
                     h->replay_nb);
@@ -1307,12 +1482,27 @@ int gpsmi_trk_replay_run_async(gpsmi_trk* h, const void* d_iq, int nb) {
 
 int gpsmi_trk_wait(gpsmi_trk* h) {
     GPSMI_REQUIRE(h, "null handle");
+    GPSMI_QUIESCE(h);
     GPSMI_HIP(hipSetDevice(h->cfg.device));
+    // only streamed steps outstanding (in line on the main stream): the event behind the latest one
+    // covers everything, and waiting for an event returns ~100 us sooner than the three stream
+    // synchronisations of the general case
+    const bool replay_busy = h->slot[0].copy_pending || h->slot[1].copy_pending || h->slot[0].timing_pending ||
+                             h->slot[1].timing_pending || h->slot[0].epi_pending || h->slot[1].epi_pending;
+    if (!replay_busy && !h->stage_used[0] && !h->stage_used[1] && (h->in_pending[0] || h->in_pending[1])) {
+        const int latest = h->stage_idx ^ 1;               // (the slot of the step enqueued last)
+        if (h->in_pending[latest]) {
+            GPSMI_HIP(hipEventSynchronize(h->in_done[latest]));
+            h->in_pending[0] = h->in_pending[1] = false;
+            return GPSMI_OK;
+        }
+    }
     return trk_settle(h);
 }
 
 int gpsmi_trk_wait_prev(gpsmi_trk* h) {
     GPSMI_REQUIRE(h, "null handle");
+    GPSMI_QUIESCE(h);
     GPSMI_HIP(hipSetDevice(h->cfg.device));
     gpsmi_trk::Slot& sl = h->slot[h->cur ^ 1];
     if (sl.copy_pending) {
@@ -1333,6 +1523,7 @@ int gpsmi_trk_replay_run(gpsmi_trk* h, const void* d_iq, int nb) {
 
 int gpsmi_trk_replay_fetch_async(gpsmi_trk* h, gpsmi_trk_out* out, size_t n) {
     GPSMI_REQUIRE(h && out, "null argument");
+    GPSMI_QUIESCE(h);
     GPSMI_REQUIRE(n <= (size_t)h->replay_nb * h->max_ch, "more records than the last replay ran");
     GPSMI_HIP(hipSetDevice(h->cfg.device));
     gpsmi_trk::Slot& sl = h->slot[h->cur];
@@ -1371,6 +1562,7 @@ int gpsmi_trk_replay(gpsmi_trk* h, const void* d_iq, int nb, const gpsmi_trk_sta
 
 int gpsmi_trk_replay_states(gpsmi_trk* h, gpsmi_trk_state* states, size_t n) {
     GPSMI_REQUIRE(h && states, "null argument");
+    GPSMI_QUIESCE(h);
     GPSMI_REQUIRE(n <= (size_t)h->replay_nb * h->max_ch,
                   "more states requested than the last replay produced");
     GPSMI_HIP(hipSetDevice(h->cfg.device));
@@ -1393,6 +1585,7 @@ int gpsmi_trk_last_codephase_ms(gpsmi_trk* h, float* ms) {
 
 int gpsmi_trk_after_acq(gpsmi_trk* later, gpsmi_acq* earlier) {
     GPSMI_REQUIRE(later && earlier, "null handle");
+    GPSMI_QUIESCE(later);
     const HandleSync e = acq_sync(earlier);
     GPSMI_REQUIRE(e.device == later->cfg.device, "handles on different devices");
     GPSMI_HIP(hipSetDevice(e.device));
@@ -1403,6 +1596,7 @@ int gpsmi_trk_after_acq(gpsmi_trk* later, gpsmi_acq* earlier) {
 
 int gpsmi_trk_set_input_format(gpsmi_trk* h, int fmt) {
     GPSMI_REQUIRE(h, "null handle");
+    GPSMI_QUIESCE(h);
     GPSMI_REQUIRE(fmt == GPSMI_IQ_C64 || fmt == GPSMI_IQ_U8, "unknown input format");
     if (fmt == GPSMI_IQ_U8 && h->mfma != 4)
         return fail(GPSMI_E_UNSUPPORTED, "raw u8 IQ input needs CODE_SAMPLES = 2048, N_CYC = 32 "
@@ -1413,6 +1607,7 @@ int gpsmi_trk_set_input_format(gpsmi_trk* h, int fmt) {
 
 int gpsmi_trk_set_streams(gpsmi_trk* h, int n_streams) {
     GPSMI_REQUIRE(h, "null handle");
+    GPSMI_QUIESCE(h);
     GPSMI_REQUIRE(n_streams >= 1 && (long long)n_streams * h->max_ch <= 65536,
                   "n_streams out of range (streams x channels <= 65536)");
     GPSMI_HIP(hipSetDevice(h->cfg.device));
@@ -1449,6 +1644,7 @@ int gpsmi_trk_set_streams(gpsmi_trk* h, int n_streams) {
 
 int gpsmi_trk_set_option(gpsmi_trk* h, const char* key, long long value) {
     GPSMI_REQUIRE(h && key, "null argument");
+    GPSMI_QUIESCE(h);
     const auto bad = [&]() { return fail(GPSMI_E_ARG, "gpsmi_trk_set_option: %s = %lld out of range", key, value); };
     if (!strcmp(key, "corr_cg")) {
         if (value != 2 && value != 4 && value != 6) return bad();
@@ -1469,6 +1665,11 @@ int gpsmi_trk_set_option(gpsmi_trk* h, const char* key, long long value) {
         h->done_by_dispatch = value != 0;
     } else if (!strcmp(key, "corr_overlap")) {
         h->corr_overlap = value != 0;
+    } else if (!strcmp(key, "stream_thread")) {
+        h->stream_thread = value != 0;
+    } else if (!strcmp(key, "stream_depth")) {
+        if (value != 2 && value != 3) return bad();
+        h->stream_depth = (int)value;
     } else if (!strcmp(key, "correlator") || !strcmp(key, "codephase") || !strcmp(key, "debug_flags")) {
         return fail(GPSMI_E_STATE, "gpsmi_trk_set_option: '%s' is taken at create time (gpsmi_set_default)", key);
     } else {
@@ -1479,6 +1680,7 @@ int gpsmi_trk_set_option(gpsmi_trk* h, const char* key, long long value) {
 
 int gpsmi_trk_get_option(gpsmi_trk* h, const char* key, long long* value) {
     GPSMI_REQUIRE(h && key && value, "null argument");
+    GPSMI_QUIESCE(h);
     if (!strcmp(key, "corr_cg")) *value = h->corr_cg;
     else if (!strcmp(key, "corr_small1")) *value = h->corr_small1;
     else if (!strcmp(key, "corr_small2")) *value = h->corr_small2;
@@ -1486,6 +1688,11 @@ int gpsmi_trk_get_option(gpsmi_trk* h, const char* key, long long* value) {
     else if (!strcmp(key, "stream_inline_max")) *value = (long long)h->stream_inline_max;
     else if (!strcmp(key, "done_by_dispatch")) *value = h->done_by_dispatch;
     else if (!strcmp(key, "corr_overlap")) *value = h->corr_overlap;
+    else if (!strcmp(key, "stream_thread")) *value = h->stream_thread;
+    else if (!strcmp(key, "stream_depth")) *value = h->stream_depth;
+    else if (!strcmp(key, "stat_stream_steps")) *value = h->stat_steps;
+    else if (!strcmp(key, "stat_stream_wait_ns")) *value = h->stat_wait_ns;
+    else if (!strcmp(key, "stat_stream_launch_ns")) *value = h->stat_launch_ns;
     else if (!strcmp(key, "correlator")) *value = (h->mfma == 4 || h->span8) ? 1 : 0;     // what runs, not what was asked
     else if (!strcmp(key, "codephase")) *value = h->general ? (h->pfa ? 0 : (h->big ? 2 : 1)) : 0;
     else if (!strcmp(key, "debug_flags")) *value = h->P.flags;
@@ -1509,6 +1716,7 @@ int gpsmi_trk_corr_wg_map(int nblocks, int ngroups, int wg, int* block, int* gro
 
 int gpsmi_trk_set_timing(gpsmi_trk* h, int on) {
     GPSMI_REQUIRE(h, "null handle");
+    GPSMI_QUIESCE(h);
     h->timing = on != 0;
     return GPSMI_OK;
 }

@@ -339,6 +339,14 @@ class TrkEngine:
         check(self.lib.gpsmi_trk_process_stream(self.h, ptr(iq), n, ptr(out)),
               'gpsmi_trk_process_stream')
 
+    def process_stream_ptr(self, iq_ptr, out_ptr):
+        """process_stream with the two addresses already as ctypes pointers (a caller that cycles
+        through a fixed ring of page-locked buffers converts them once): no checks here, the
+        library checks the sample count and refuses what it cannot read."""
+        rc = self.lib.gpsmi_trk_process_stream(self.h, iq_ptr, self.streams * self.cfg.ngps, out_ptr)
+        if rc:
+            check(rc, 'gpsmi_trk_process_stream')
+
     def replay(self, d_iq, nb, table, delay_used=None):
         """nb device-resident blocks, states at block start [nb, max_ch]."""
         table = np.ascontiguousarray(table, dtype=STATE_DTYPE)

@@ -131,7 +131,7 @@ def eval_gps_bits(gps_bits, smp_times):
         return result, gps_bits, smp_times
     gb = np.copy(gps_bits)
     corr = np.correlate(gb, PREAMBLE_PM, mode='same')
-    loc = [i - 4 for i in range(len(corr)) if abs(corr[i]) == 8]
+    loc = (np.flatnonzero(np.abs(corr) == 8) - 4).tolist()
     start = 0
     if loc:
         gb[gb == -1] = 0

@@ -103,14 +103,18 @@ class Receiver:
         ngps = self.cfg.ngps
         cp = batch.code_phase                        # [K][satellites in actSatSet order]
         good = cp >= 0
-        stream_nos = [t // ngps for t in batch.smp_times]
-        first = np.where(good.any(axis=0), good.argmax(axis=0), len(stream_nos))
+        stream_nos = [t // ngps for t in batch.smp_times]       # (np.int64, as SMP_TIME//NGPS is there)
+        n_good = good.sum(axis=0)
+        first = np.where(n_good > 0, good.argmax(axis=0), len(stream_nos))
+        cols = cp.T.tolist()
         for col in np.argsort(first, kind='stable').tolist():
-            if first[col] == len(stream_nos):
+            if n_good[col] == 0:
                 break
             lst = self.co_ph_lst.setdefault(batch.sats[col], [])
-            for k in np.flatnonzero(good[:, col]).tolist():
-                lst.append((stream_nos[k], float(cp[k, col])))
+            if n_good[col] == len(stream_nos):
+                lst.extend(zip(stream_nos, cols[col]))
+            else:
+                lst.extend((stream_nos[k], cols[col][k]) for k in np.flatnonzero(good[:, col]).tolist())
         frame_lst = []
         for sw_fq, sat_no, f_lst, co_ph, cp_q in batch.res:
             frame_lst += f_lst

@@ -34,9 +34,10 @@ import numpy as np
 
 from . import navbits
 from .acquisition import norm_max_corr
-from .engine import OUT_DTYPE, AcqEngine, Config, PinnedArray, TrkEngine
+from .engine import OUT_DTYPE, AcqEngine, Config, PinnedArray, TrkEngine, ptr
 
 MIN_CORR_Q = -0.9                      # gpslib.py:1048
+GPSMI_MAX_DUMPS = 33                   # N_CYC + 1 (gpsmi.h)
 
 
 def fit_code_phase(lo, pk, hi, mx):
@@ -132,7 +133,7 @@ class HostChannel:
         if len(self.EDGES) > 2:
             t1, st1 = self.EDGES[1]
             for t2, st2 in self.EDGES[2:]:
-                m, r = np.divmod(t2 - t1, 20)
+                m, r = divmod(t2 - t1, 20)
                 if r > 17:
                     m += 1
                 if m > 0:
@@ -156,53 +157,42 @@ class HostChannel:
     # ---- the tracking branch of process() after the GPU work (gpslib.py:1178-1208)
     def absorb(self, rec, smp_time):
         """rec: one gpsmi_trk_out record of this channel for the block."""
-        recs = np.empty(1, dtype=rec.dtype)
-        recs[0] = rec
-        trig, frames, cps = self.absorb_many(recs, [smp_time])
+        recs = np.empty((1, 1), dtype=rec.dtype)
+        recs[0, 0] = rec
+        trig, frames, cps = self.absorb_many(recs[:, 0], [smp_time])
         return trig, frames, cps[0]
 
     def absorb_many(self, recs, smp_times):
         """recs: the records of this channel for K consecutive tracking blocks (a 1-D structured
         array), smp_times their SMP_TIMEs.  Only the last block may be a report block (the caller
         absorbs at every one).  -> (sweep trigger, frameLst of the last block, [codePhase] * K)."""
+        x = extract_records(recs.reshape(len(recs), 1), [self], smp_times, self.cfg.code_samples)
+        return self.absorb_extracted(x, 0, smp_times)
+
+    def absorb_extracted(self, x, col, smp_times):
+        """The same from the lists extract_records pulled out of a [K, channels] record array in
+        one vectorised pass; col = this channel's column there."""
         cfg = self.cfg
         cs = cfg.code_samples
-        k_last = len(recs) - 1
-        cps = recs['code_phase'].tolist()
-        self.CORR_Q, self.CORR_L = self.corrQualityMany([-1 if v < 0 else 1 for v in cps])
+        cps = x.code_phase[col]
+        self.CORR_Q, self.CORR_L = self.corrQualityMany(x.corr[col])
         # decodeData's edges (gpslib.py:1421-1436) from the device's scan: bit i of a record's mask
         # = dump i is an edge, at (MS_TIME before the block + i, ST + n0 of window i)
-        msc = recs['ms_count']
-        if msc.any():                                   # PHASE_LOCKED was set before some block
-            events = np.flatnonzero((recs['edge_mask'] != 0) | (recs['edge_mask_hi'] != 0)
-                                    | (recs['edge_sign0'] != 0))
-            for j in events.tolist():
-                r = recs[j]
-                if self.EDGES[0] == 0 and r['edge_sign0'] != 0:
-                    self.EDGES[0] = np.float32(r['edge_sign0'])     # np.sign(m.real), :1424-1426
-                mask = int(r['edge_mask']) | (int(r['edge_mask_hi']) << 32)
-                if mask:
-                    ms0 = self.MS_TIME + int(msc[:j].sum())
-                    delay = int(r['delay_used'])
-                    nps = int(recs[j - 1]['nps']) if j else self.nps
-                    first = int(r['first_len'])                     # n1 of the first window
-                    st = smp_times[j] if nps + delay == 0 else smp_times[j] + delay - cs
-                    while mask:
-                        i = (mask & -mask).bit_length() - 1
-                        mask &= mask - 1
-                        self.EDGES.append((ms0 + i, st + (first + (i - 1) * cs if i else 0)))
-            self.MS_TIME += int(msc.sum())
-        last = recs[k_last]
-        self.SMP_TIME = smp_times[k_last]
+        lo, hi = x.ev_lo[col], x.ev_lo[col + 1]
+        if self.EDGES[0] == 0 and x.sg_lo[col + 1] > x.sg_lo[col]:
+            self.EDGES[0] = np.float32(x.sign0[x.sg_lo[col]])       # np.sign(m.real), :1424-1426
+        if hi > lo:
+            self.EDGES.extend(x.edges[lo:hi])
+        self.MS_TIME += x.ms_total[col]
+        self.SMP_TIME = smp_times[-1]
         stream_no = self.SMP_TIME // cfg.ngps
-        self.DELAY = int(last['delay_used'])
-        self.STD_DEV = last['std_dev']
-        self.AMPLITUDE = last['amplitude']
-        self.MAX_CORR = last['norm_max_corr']
-        if k_last:                                      # the lock flag and FREQ the report sees are
-            prev = recs[k_last - 1]                     # those before the last block's PLL (:1192-1208)
-            self.PHASE_LOCKED = bool(prev['phase_locked'])
-            self.FREQ = prev['freq']
+        self.DELAY = x.last_delay[col]
+        self.STD_DEV = x.last_std[col]
+        self.AMPLITUDE = x.last_amp[col]
+        self.MAX_CORR = x.last_norm[col]
+        if x.prev_locked is not None:                   # the lock flag and FREQ the report sees are
+            self.PHASE_LOCKED = x.prev_locked[col]      # those before the last block's PLL (:1192-1208)
+            self.FREQ = x.prev_freq[col]
         frames, sweep = [], False
         if stream_no % self.NO_SEC == 0:
             if self.PHASE_LOCKED:
@@ -211,11 +201,69 @@ class HostChannel:
                 frames = [{}]
             self.reportValues(frames)
             sweep = self.checkCorrQuality()
-        self.nps = int(last['nps'])
+        self.nps = x.last_nps[col]
         if not sweep:
-            self.PHASE_LOCKED = bool(last['phase_locked'])
-            self.FREQ = last['freq']
+            self.PHASE_LOCKED = x.last_locked[col]
+            self.FREQ = x.last_freq[col]
         return sweep, frames, cps
+
+
+class Extracted:
+    """Plain Python data of a [K blocks, W channels] record array (see extract_records)."""
+    __slots__ = ('code_phase', 'corr', 'ms_total', 'ev_lo', 'edges', 'sg_lo', 'sign0', 'last_delay',
+                 'last_std', 'last_amp', 'last_norm', 'last_nps', 'last_locked', 'last_freq',
+                 'prev_locked', 'prev_freq', 'cp_array')
+
+
+def extract_records(recs, chans, smp_times, cs):
+    """One vectorised pass over recs [K, W] (K consecutive blocks, W channels; chans[w] the
+    HostChannel of column w -- None for a free slot, whose records are all-zero -- for MS_TIME
+    and len(PREV_SAMPLES) before the first block) -> the
+    per-channel lists HostChannel.absorb_extracted consumes.  The numpy calls are per batch, not
+    per channel: a dozen channels cost what one costs."""
+    x = Extracted()
+    k, w = recs.shape
+    cp = recs['code_phase']
+    x.cp_array = cp
+    x.code_phase = cp.T.tolist()
+    x.corr = np.where(cp < 0, -1, 1).T.tolist()        # corrQuality's +-1 per block (:1331-1333)
+    msc = recs['ms_count']
+    x.ms_total = msc.sum(axis=0).tolist()
+    em, eh, s0 = recs['edge_mask'], recs['edge_mask_hi'], recs['edge_sign0']
+    # every edge of the batch at once: (channel, block) pairs with a non-empty mask, then their set bits
+    masks = em.T.astype(np.uint64) | (eh.T.astype(np.uint64) << np.uint64(32))          # [W, K]
+    ev_w, ev_j = np.nonzero(masks)                      # by channel, then block
+    x.edges, x.ev_lo = [], [0] * (w + 1)
+    if len(ev_w):
+        ms0 = np.array([int(hc.MS_TIME) if hc else 0 for hc in chans], dtype=np.int64)
+        nps0 = np.array([hc.nps if hc else 0 for hc in chans], dtype=np.int64)
+        bits = (masks[ev_w, ev_j][:, None] >> np.arange(GPSMI_MAX_DUMPS, dtype=np.uint64)[None, :]) & np.uint64(1)
+        e_n, e_i = np.nonzero(bits)                     # event n, dump i (ascending within an event)
+        bw, bj = ev_w[e_n], ev_j[e_n]
+        ms = (ms0[None, :] + np.cumsum(msc, axis=0) - msc)[bj, bw] + e_i
+        delay = recs['delay_used'][bj, bw].astype(np.int64)
+        nps_before = np.where(bj > 0, recs['nps'][np.maximum(bj - 1, 0), bw], nps0[bw])
+        smp = np.asarray(smp_times, dtype=np.int64)[bj]
+        st = np.where(nps_before + delay == 0, smp, smp + delay - cs)        # ST of decodeData (:1408-1416)
+        first = recs['first_len'][bj, bw].astype(np.int64)                   # n1 of the first window
+        n0 = np.where(e_i > 0, first + (e_i - 1) * cs, 0)                    # n0 of window i
+        x.edges = list(zip(ms.tolist(), (st + n0).tolist()))
+        x.ev_lo = np.searchsorted(bw, np.arange(w + 1)).tolist()
+    sg_w, sg_j = np.nonzero(s0.T)                       # blocks that stored a sign into EDGES[0]
+    x.sg_lo = np.searchsorted(sg_w, np.arange(w + 1)).tolist()
+    x.sign0 = s0.T[sg_w, sg_j].tolist()
+    last = recs[k - 1]
+    x.last_delay = last['delay_used'].tolist()
+    x.last_nps = last['nps'].tolist()
+    x.last_locked = (last['phase_locked'] != 0).tolist()
+    x.last_std, x.last_amp = last['std_dev'].copy(), last['amplitude'].copy()   # (np.float32 elements)
+    x.last_norm, x.last_freq = last['norm_max_corr'].copy(), last['freq'].copy()
+    x.prev_locked = x.prev_freq = None
+    if k > 1:
+        prev = recs[k - 2]
+        x.prev_locked = (prev['phase_locked'] != 0).tolist()
+        x.prev_freq = prev['freq'].copy()
+    return x
 
 
 class Batch:
@@ -247,7 +295,11 @@ class GpuPool:
         self.pending, self.pending_order = [], None
         self.done = []                      # batches absorbed on the side (by a pool operation
                                             # that needed the host state), for the next satCalcLazy
-        self.streamed = hasattr(self.trk, 'process_stream')
+        self.streamed = hasattr(self.trk, 'process_stream_ptr')
+        # the steady state of satCalcLazy: the stream number of the last block enqueued for exactly
+        # `steady_act` / `steady_worker` with no channel in its sweep (None: look at every channel)
+        self.steady_no, self.steady_act, self.steady_worker, self.steady_order = None, None, None, None
+        self.corr_len_max = 0               # longest CORRLST among the channels of the last batch absorbed
         self.in_ring, self.out_ring, self.n_fed = None, None, 0
         self.rows = [None] * self.RING      # (a stand-in engine's records, tests)
 
@@ -266,22 +318,30 @@ class GpuPool:
         if self.streamed:
             want = np.uint16 if self.raw_u8 else np.complex64
             if self.in_ring is None:
-                # three page-locked input buffers: gpsmi_trk_process_stream returns once the step
-                # before last is done, so the buffer of the call three back is free (gpsmi.h)
-                self.in_ring = [PinnedArray((self.cfg.ngps,), want) for _ in range(3)]
+                # four page-locked input buffers: with "stream_depth" = 3 gpsmi_trk_process_stream
+                # returns once the step three calls back is done, so the buffer of the call four back
+                # is free (gpsmi.h); the host prepares block k + 1 while block k is being enqueued
+                self.trk.set_option('stream_depth', 3)
+                self.in_ring = [PinnedArray((self.cfg.ngps,), want) for _ in range(4)]
                 self.out_ring = PinnedArray((self.RING, self.pool_no), OUT_DTYPE)
+                # (the addresses the library is called with, made once: ctypes conversions cost
+                # microseconds apiece)
+                self.in_ptr = [ptr(p.array) for p in self.in_ring]
+                self.out_ptr = [ptr(self.out_ring.array[r]) for r in range(self.RING)]
             data = np.asarray(data)
             if data.dtype != want:          # a silent cast would turn one format into garbage of the other
                 raise TypeError(f'block dtype {data.dtype} does not match the input format '
                                 f'({np.dtype(want).name})')
-            buf = self.in_ring[self.n_fed % 3].array
+            j = self.n_fed % 4
+            buf = self.in_ring[j].array
             np.copyto(buf, data.reshape(buf.shape))
-            self.trk.process_stream(buf, self.out_ring.array[row])
+            self.trk.process_stream_ptr(self.in_ptr[j], self.out_ptr[row])
             self.n_fed += 1
         else:
             self.rows[row] = self.trk.process(data)
         self.pending.append((smp_time, row))
         self.pending_order = order
+        self.last_stream_no = smp_time // self.cfg.ngps
 
     # ---- everything that is pending -> host state; the batch goes to `done`
     def absorb_pending(self):
@@ -300,13 +360,18 @@ class GpuPool:
         order = self.pending_order
         self.pending, self.pending_order = [], None
         res, trig = [], []
-        cp = np.empty((k, len(order)))
-        for col, (sno, wno) in enumerate(order):
+        x = extract_records(recs, self.chan, smp, self.cfg.code_samples)   # (all worker slots: column = slot)
+        cp = x.cp_array[:, [wno for _, wno in order]]
+        stream_no = smp[-1] // self.cfg.ngps
+        self.corr_len_max = 0
+        for sno, wno in order:
             hc = self.chan[wno]
-            t, frames, cps = hc.absorb_many(recs[:, wno], smp)
-            cp[:, col] = cps
+            hc.PREV_STREAM_NO = stream_no
+            t, frames, cps = hc.absorb_extracted(x, wno, smp)
             if t:
                 trig.append(wno)
+            if len(hc.CORRLST) > self.corr_len_max:
+                self.corr_len_max = len(hc.CORRLST)
             res.append([hc, sno, frames, cps[-1]])
         for wno in trig:                                # initSweep (gpslib.py:1110-1116) with the
             initSweep(self, wno, self.saved.pop(wno))   # state before this block's PLL update
@@ -345,6 +410,7 @@ def closeMultiProcPool(pool):               # gpsrecv.py:363-367
 def open_worker(pool, wno, sat_no, freq, delay):
     """('initInst',(satNo,freq,delay)) for worker slot wno (gpsrecv.py:312-321)."""
     pool.absorb_pending()
+    pool.steady_no = None
     pool.trk.open(wno, sat_no, freq, delay)
     pool.chan[wno] = HostChannel(sat_no, freq, delay, pool.cfg)
     return sat_no
@@ -353,6 +419,7 @@ def open_worker(pool, wno, sat_no, freq, delay):
 def close_worker(pool, wno):
     """('delInst',None) (gpsrecv.py:323-328) -> whether an instance existed."""
     pool.absorb_pending()
+    pool.steady_no = None
     had = pool.chan[wno] is not None
     if had and not pool.chan[wno].SWEEP:
         pool.trk.close_channel(wno)
@@ -414,6 +481,7 @@ def initSweep(pool, wno, st=None):
     remember FREQ and DF (st: the engine state to fall back to, default the current
     one), unlock, restart at MIN_FREQ; the engine channel is closed until the sweep ends."""
     pool.absorb_pending()
+    pool.steady_no = None
     hc = pool.chan[wno]
     if st is None:
         st = pool.trk.get_state(wno)
@@ -430,6 +498,7 @@ def _sat_calc(actSatSet, pool, poolWorker, data, smpTime, sweep=()):
     """One block for every active satellite, waited for: tracking channels through the engine,
     sweeping ones through the acquisition engine -> Batch of one block."""
     pool.absorb_pending()                               # (earlier lazy blocks go to pool.done)
+    pool.steady_no = None
     cfg = pool.cfg
     stream_no = smpTime // cfg.ngps
     order = [(sno, poolWorker.index(sno)) for sno in actSatSet]
@@ -515,24 +584,38 @@ def satCalcLazy(actSatSet, pool, poolWorker, data, smpTime):
     per-block path of satCalc; the results are the same either way."""
     cfg = pool.cfg
     stream_no = smpTime // cfg.ngps
+    no_sec = 1024 // cfg.n_cyc
+    report = stream_no % no_sec == 0
+    # steady state: the block before went the plain way for the same satellites in the same worker
+    # slots, so no channel is in its sweep and none has a gap; only a report block that could trigger
+    # a sweep (a minute of correlation history, gpslib.py:1134-1138) needs a look at the channels
+    if (pool.steady_no is not None and stream_no - 1 == pool.steady_no and actSatSet == pool.steady_act
+            and poolWorker == pool.steady_worker
+            and not (report and pool.corr_len_max + len(pool.pending) + 1 >= 60 * no_sec)):
+        pool.saved = {}
+        pool.submit(data, smpTime, pool.pending_order or pool.steady_order)
+        pool.steady_no = stream_no
+        if report:
+            pool.absorb_pending()
+        return pool.take_done()
     order = [(sno, poolWorker.index(sno)) for sno in actSatSet]
-    report = stream_no % (1024 // cfg.n_cyc) == 0
     plain = len(order) > 0 and (pool.pending_order is None or pool.pending_order == order)
     if plain:
         n_pend = len(pool.pending)
         for _, wno in order:
             hc = pool.chan[wno]
-            if (hc.SWEEP or stream_no - 1 != hc.PREV_STREAM_NO
+            if (hc.SWEEP or stream_no - 1 != hc.PREV_STREAM_NO + n_pend
                     or (report and len(hc.CORRLST) + n_pend + 1 >= hc.CORRLST_NO)):
                 plain = False
                 break
     if not plain:
         b = _sat_calc(actSatSet, pool, poolWorker, data, smpTime)
         return pool.take_done() + [b]
-    for _, wno in order:
-        pool.chan[wno].PREV_STREAM_NO = stream_no
     pool.saved = {}
     pool.submit(data, smpTime, order)
+    pool.steady_no, pool.steady_act, pool.steady_worker = stream_no, set(actSatSet), list(poolWorker)
+    pool.steady_order = order
+    pool.corr_len_max = max(len(pool.chan[w].CORRLST) for _, w in order)
     if report:
         pool.absorb_pending()
     return pool.take_done()

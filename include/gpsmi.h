@@ -87,7 +87,14 @@ int gpsmi_abi_sizeof(int which);
  *                       completion signal; 0: on an event record behind it
  *   "corr_overlap"      1: gpsmi_trk_replay_run_async queues a batch's code-phase correlation on a
  *                       second stream, so that it runs beside the previous batch's correlator
- *                       (throughput mode; 0, the default, keeps every kernel alone on the chip) */
+ *                       (throughput mode; 0, the default, keeps every kernel alone on the chip)
+ *   "stream_thread"     1 (default): the launches of a gpsmi_trk_process_stream step are made by a
+ *                       submission thread of the handle while the caller prepares its next block
+ *                       (they cost as much host time as the step takes on the GPU); 0: by the caller
+ *   "stream_depth"      2 (default): gpsmi_trk_process_stream returns once the step of the call
+ *                       BEFORE LAST is complete (three caller buffers in rotation); 3: the step three
+ *                       calls back (four buffers) -- with the submission thread the caller then hands
+ *                       over block k + 1 while block k is still being enqueued              */
 int gpsmi_set_default(const char* key, long long value);
 int gpsmi_clear_default(const char* key);
 int gpsmi_device_count(int* n);

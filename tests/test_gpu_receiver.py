@@ -163,3 +163,85 @@ def test_worker_message_loop_equals_direct_calls(golden_default):
     # (the swept channel found its satellite again: a hit inside the first call ends the sweep at once)
     assert not any(r[0] for r in out_a[-1])
     assert out_a[4][[r[1] for r in out_a[4]].index(w_a[0])][3] != out_a[3][[r[1] for r in out_a[3]].index(w_a[0])][3]
+
+
+def test_lazy_blocks_equal_per_block_calls(golden_default):
+    """receiver.satCalcLazy (blocks enqueued on the device, the host absorbing a second of records
+    at a time) against receiver.satCalc block by block on the same blocks: the result list of every
+    report block, the code phases of every block, the edge lists and counters of every channel and
+    the engine state at the end are the same."""
+    from gpsmi import receiver as R
+    g = golden_default
+    nch, nb = 12, 80
+    found = [(n, int(s), f, int(d)) for n, s, f, d in (tuple(r) for r in g['sweep_found'])]
+    blocks = scene_blocks('default', 5, 48)
+    runs = []
+    for lazy in (False, True):
+        pool, pool_no, worker = R.initMultiProcPool(nch)
+        worker, act = R.initPoolStreams(pool, pool_no, worker, set(), {s for _, s, _, _ in found[:nch]}, found)
+        res, cps = [], []
+        for i in range(nb):
+            smp = np.int64((5 + i + 1) * 65536)
+            blk = blocks[i % 48]
+            if lazy:
+                for b in R.satCalcLazy(act, pool, worker, blk, smp):
+                    if any(x[2] for x in b.res):
+                        res.append(b.res)
+                    cps.append(b.code_phase)
+            else:
+                r = R.satCalc(act, pool, worker, blk, smp)
+                cps.append(np.array([[x[3] for x in r]]))
+                if any(x[2] for x in r):
+                    res.append(r)
+        pool.absorb_pending()
+        for b in pool.take_done():
+            cps.append(b.code_phase)
+        chans = [(hc.MS_TIME, list(hc.EDGES), hc.nps, hc.DELAY, bool(hc.PHASE_LOCKED), float(hc.FREQ),
+                  list(hc.CORRLST)) for hc in pool.chan]
+        states = [pool.trk.get_state(w).tobytes() for w in range(nch)]
+        runs.append((res, np.concatenate(cps), chans, states, worker))
+        R.closeMultiProcPool(pool)
+    (res_a, cp_a, ch_a, st_a, w_a), (res_b, cp_b, ch_b, st_b, w_b) = runs
+    assert w_a == w_b and len(res_a) == len(res_b) == 2          # blocks 32 and 64 of the stream
+    assert cp_a.shape == cp_b.shape == (nb, nch) and np.array_equal(cp_a, cp_b)
+    for ra, rb in zip(res_a, res_b):
+        assert [(x[0], x[1], x[3], tuple(map(float, x[4]))) for x in ra] == \
+               [(x[0], x[1], x[3], tuple(map(float, x[4]))) for x in rb]
+        assert [[sorted(d.items(), key=str) for d in x[2]] for x in ra] == \
+               [[sorted(d.items(), key=str) for d in x[2]] for x in rb]
+    assert ch_a == ch_b
+    assert st_a == st_b
+    assert any(len(c[1]) > 3 for c in ch_a)                     # edges were found
+
+
+def test_a_subset_call_leaves_the_other_channels_alone(golden_default):
+    """The reference's workers are independent processes: running some of them on a block and the
+    others later (a partial runInst burst) gives what running all of them at once gives.  Here the
+    engine advances every open channel per call, so a call for a subset puts the others' state rows
+    back (receiver._sat_calc)."""
+    from gpsmi import receiver as R
+    g = golden_default
+    nch = 6
+    found = [(n, int(s), f, int(d)) for n, s, f, d in (tuple(r) for r in g['sweep_found'])]
+    blocks = scene_blocks('default', 5, 8)
+    outs = []
+    for split in (False, True):
+        pool, pool_no, worker = R.initMultiProcPool(nch)
+        worker, act = R.initPoolStreams(pool, pool_no, worker, set(), {s for _, s, _, _ in found[:nch]}, found)
+        order = list(act)
+        run = []
+        for i in range(8):
+            smp = np.int64((5 + i + 1) * 65536)
+            if split and i in (3, 6):
+                first = R.satCalc(order[:2], pool, worker, blocks[i], smp)
+                late = R.satCalc(order[2:], pool, worker, blocks[i], smp)
+                run.append(first + late)
+            else:
+                run.append(R.satCalc(order, pool, worker, blocks[i], smp))
+        outs.append((run, [pool.trk.get_state(w).tobytes() for w in range(nch)]))
+        R.closeMultiProcPool(pool)
+    (run_a, st_a), (run_b, st_b) = outs
+    for ra, rb in zip(run_a, run_b):
+        assert [(x[0], x[1], x[3], tuple(map(float, x[4]))) for x in ra] == \
+               [(x[0], x[1], x[3], tuple(map(float, x[4]))) for x in rb]
+    assert st_a == st_b
