@@ -548,6 +548,9 @@ def main():
                     help='blocks the drop-in leg feeds through pipeline.Receiver.feed (20 s of signal)')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the configs[3] / configs[4] legs')
+    ap.add_argument('--overlap', action='store_true',
+                    help='time the overlapped pipeline (option "corr_overlap": consecutive batches on two '
+                         'streams) instead of the isolated one; either way both are measured and reported')
     ap.add_argument('--shard', choices=('time', 'channels'), default='time',
                     help='N > 1: how the tracking work is split over the ranks')
     ap.add_argument('--rehearse', action='store_true',
@@ -704,11 +707,17 @@ def main():
     acq_n = acq_navg * 2048
 
     cold_corr_ms, cp_ms = [], []
+    ovl = {'total': [], 'corr': [], 'cp': []}      # the same kernels' times inside the overlapped pipeline
 
     def record_last(cold=False):
         t, c = trk.last_ms()
-        if cold:
+        if cold == 'cold':
             cold_corr_ms.append(c)
+            return
+        if cold == 'overlapped':
+            ovl['total'].append(t)
+            ovl['corr'].append(c)
+            ovl['cp'].append(trk.last_codephase_ms())
             return
         total_ms.append(t)
         corr_ms.append(c)
@@ -755,7 +764,7 @@ def main():
         trk.replay_fetch_async(pins[k & 1].array)
         trk.wait_prev()
         if record and k > 0 and (k - 1) % TIMED_EVERY == 0:
-            record_last(cold=record == 'cold')
+            record_last(cold=record)
 
     # Settling: an idle MI355X needs some 40 ms under load before its clocks stop moving - the
     # same correlator launch takes ~120 us at the start of a run and ~103 us from the 100th
@@ -765,11 +774,23 @@ def main():
     # W warm-up steps and the K timed steps follow unchanged.
     # (the correlator launches of the first 24 of them are timed: `roofline.frac_cold`, what a run
     # that starts its clock on an idle device sees)
+    # Two pipelines over the same step, both measured in every run and both named in the JSON line.
+    # ISOLATED (the default for the timed region): one batch at a time, every kernel alone on the chip,
+    # its duration is what a roofline can be quoted on.  OVERLAPPED (option "corr_overlap"): consecutive
+    # batches alternate between two streams, so that the code-phase correlation of batch k + 1 is
+    # eligible while the correlator of batch k runs.  The pass that is not timed for `value` runs
+    # OVL_STEPS steps behind the timed region.  (Measured: the overlapped pipeline is 2-7 % SLOWER here;
+    # DESIGN.md section 4.6 has the arithmetic -- the two big kernels both live on SIMD issue slots and
+    # cannot share a CU's LDS -- so the isolated one stays the default.)
+    overlap = a.overlap
+    OVL_STEPS = 24
     for k in range(a.settle_steps):
         step(k, 'cold' if k < 26 else False)
     if a.settle_steps:
         finish_search()
         trk.wait()
+    if overlap:
+        trk.set_option('corr_overlap', 1)
     for k in range(a.warmup):
         step(k, False)
     if a.warmup:
@@ -779,13 +800,30 @@ def main():
     recording[0] = True
     t0 = time.perf_counter()
     for k in range(a.steps):
-        step(k, True)
+        step(k, 'overlapped' if overlap else True)
     finish_search()                         # the last step: its search, ...
     trk.wait()                              # ... its kernels and its copy
     barrier()
     dt = time.perf_counter() - t0
     if (a.steps - 1) % TIMED_EVERY == 0:
-        record_last()
+        record_last('overlapped' if overlap else False)
+    recording[0] = False
+    # the other pipeline, OVL_STEPS steps (untimed for `value`)
+    trk.set_option('corr_overlap', 0 if overlap else 1)
+    for k in range(4):
+        step(k, False)
+    finish_search()
+    trk.wait()
+    E.sync(local)
+    recording[0] = overlap                  # (the search's own time belongs to the isolated pipeline)
+    t1 = time.perf_counter()
+    for k in range(OVL_STEPS):
+        step(k, True if overlap else 'overlapped')
+    finish_search()
+    trk.wait()
+    other_ms_step = (time.perf_counter() - t1) / OVL_STEPS * 1e3
+    recording[0] = False
+    trk.set_option('corr_overlap', 0)
     trk.set_timing(True)
     if dist is not None:
         dt_mine = dt
@@ -882,13 +920,29 @@ def main():
                 'sharding': sharding_txt,
             },
             'x_realtime': round(value / 2.048, 1),
+            'pipeline': {
+                'timed': ('overlapped: consecutive batches alternate between two streams (option '
+                          '"corr_overlap"), the code-phase correlation of batch k + 1 runs beside the '
+                          'correlator of batch k') if overlap else
+                         'isolated: one batch at a time, every kernel alone on the chip',
+                'isolated_ms_per_step': round(other_ms_step if overlap else ms_step, 4),
+                'overlapped_ms_per_step': round(ms_step if overlap else other_ms_step, 4),
+                'note': f'the pipeline that is not the timed one ran {OVL_STEPS} steps behind the timed region; '
+                        'roofline.kernel_ms and kernels_ms are the isolated pipeline\'s (every kernel alone '
+                        'on the chip)',
+                'overlapped_kernels_ms': ({'tracking_all': round(float(np.mean(ovl['total'])), 4),
+                                           'correlator': round(float(np.mean(ovl['corr'])), 4),
+                                           'codephase_correlation': round(float(np.mean(ovl['cp'])), 4)}
+                                          if ovl['corr'] else None),
+            },
             'roofline': {
                 'bound': 'hbm', 'kernel': 'trk_span_kernel',
                 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
                 'traffic': traffic, 'traffic_source': traffic_src,
                 'kernel_ms': round(k_ms, 4),
-                'kernel_ms_source': 'hipExtLaunchKernel begin/end events, mean of the timed steps',
+                'kernel_ms_source': 'hipExtLaunchKernel begin/end events, mean over the timed steps of the '
+                                    'isolated pass (the kernel alone on the chip, steady clocks)',
                 'algorithmic_bytes_per_launch': alg_bytes,
                 'frac_vs_measured_copy': round(achieved / HBM_COPY_GBS, 4),
                 'frac_cold': round(alg_bytes / (float(np.mean(cold_corr_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)

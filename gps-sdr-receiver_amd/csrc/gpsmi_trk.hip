@@ -476,6 +476,7 @@ struct gpsmi_trk {
                                          // at 96, 81 against 66 at 128)
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;   // result read-back, overlaps the next replay run
+    hipStream_t alt_stream = nullptr;    // "corr_overlap": the runs of result slot 1 (slot 0 keeps `stream`)
     hipStream_t epi_stream = nullptr;    // replay: the epilogue of run k beside the code-phase
                                          // correlation of run k + 1 (the other slot's buffers)
     // streaming from host memory (gpsmi_trk_process_stream): two staging blocks filled on a stream
@@ -501,6 +502,7 @@ struct gpsmi_trk {
         bool copy_pending = false, timing_pending = false, epi_pending = false;
         JobMid* d_mid = nullptr;             // per-job descriptors and window sums of the slot's run
         float2* d_partial = nullptr;
+        hipStream_t run_stream = nullptr;    // "corr_overlap": the stream the slot's runs are enqueued on (null: h->stream)
         float* d_rec = nullptr;              // raw sums of the single-block span correlator (gpsmi_trk_span.h):
                                              // per slot, the epilogue of run k reads them on its own stream
                                              // while run k + 1 writes the other slot's
@@ -627,11 +629,14 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
                       int njobs, int nch, bool side_epilogue = false) {
     TrkParams P = h->P;
     P.nch = nch;
+    // the stream this launch goes to: the handle's, or ("corr_overlap") the slot's own, so that the
+    // code-phase correlation of this batch may run beside the correlator of the batch before
+    hipStream_t rs = sl.run_stream ? sl.run_stream : h->stream;
     h->main_tail = nullptr;
     const float2* d_iq = static_cast<const float2*>(d_iq_v);       // (raw uint16 when iq_fmt says so)
     const bool u8 = h->iq_fmt == GPSMI_IQ_U8;
     const bool timed = h->timing;        // each event record is a barrier packet (~5 us of bubble)
-    if (timed) GPSMI_HIP(hipEventRecord(sl.ev[0], h->stream));
+    if (timed) GPSMI_HIP(hipEventRecord(sl.ev[0], rs));
     const int nblocks = njobs / nch;
     const int ngroups = (nch + kGroupCh - 1) / kGroupCh;
     const dim3 sgrid(((nblocks + 7) / 8) * 8 * ngroups);
@@ -643,22 +648,22 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
     if (h->general) {
         const int cs = P.cs;
         hipLaunchKernelGGL(trk_fold_general_kernel, dim3((cs + 255) / 256, nblocks), dim3(256), 0,
-                           h->stream, d_iq, h->d_t32, st_in, P, h->d_fold, h->d_xsel, h->d_rsel,
+                           rs, d_iq, h->d_t32, st_in, P, h->d_fold, h->d_xsel, h->d_rsel,
                            sl.d_mid);
         if (h->pfa)              // transform, product, transform and statistics in one launch
-            pfa_corr_launch(h->stream, h->d_fold, h->d_xsel, h->d_rsel, njobs, h->d_RSp, h->d_stats);
+            pfa_corr_launch(rs, h->d_fold, h->d_xsel, h->d_rsel, njobs, h->d_RSp, h->d_stats);
         else if (h->big)
-            big_corr_launch(h->stream, h->d_fold, h->d_xsel, h->d_rsel, njobs, cs, h->d_RS, h->d_S,
+            big_corr_launch(rs, h->d_fold, h->d_xsel, h->d_rsel, njobs, cs, h->d_RS, h->d_S,
                             h->d_tw, h->d_twN, h->d_mag);
         else
             hipLaunchKernelGGL(circ_corr_direct_kernel,
                                dim3((cs + kDirLagsPerWg - 1) / kDirLagsPerWg, njobs), dim3(256), 0,
-                               h->stream, h->d_fold, h->d_code, h->d_xsel, h->d_rsel, cs,
+                               rs, h->d_fold, h->d_code, h->d_xsel, h->d_rsel, cs,
                                h->d_mag);
         if (!h->pfa)
-            hipLaunchKernelGGL(corr_stats_kernel, dim3(njobs), dim3(256), 0, h->stream, h->d_mag, cs,
+            hipLaunchKernelGGL(corr_stats_kernel, dim3(njobs), dim3(256), 0, rs, h->d_mag, cs,
                                h->d_stats);
-        hipLaunchKernelGGL(trk_decide_kernel, dim3((njobs + 255) / 256), dim3(256), 0, h->stream,
+        hipLaunchKernelGGL(trk_decide_kernel, dim3((njobs + 255) / 256), dim3(256), 0, rs,
                            h->d_stats, forced, P, njobs, sl.d_out, sl.d_mid);
     } else {
         // channels per correlation workgroup: fewer channels = fewer live accumulators
@@ -673,10 +678,10 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
 #define GPSMI_LAUNCH_CORR(CGV)                                                                          \
     do {                                                                                              \
         if (u8)                                                                                       \
-            hipLaunchKernelGGL((trk_corr_kernel<CGV, 1>), cgrid, dim3(256), 0, h->stream, d_iq_v,     \
+            hipLaunchKernelGGL((trk_corr_kernel<CGV, 1>), cgrid, dim3(256), 0, rs, d_iq_v,     \
                                st_in, forced, h->d_rep, h->d_tw, P, ng, nblocks, sl.d_out, sl.d_mid); \
         else                                                                                          \
-            hipLaunchKernelGGL((trk_corr_kernel<CGV, 0>), cgrid, dim3(256), 0, h->stream, d_iq_v,     \
+            hipLaunchKernelGGL((trk_corr_kernel<CGV, 0>), cgrid, dim3(256), 0, rs, d_iq_v,     \
                                st_in, forced, h->d_rep, h->d_tw, P, ng, nblocks, sl.d_out, sl.d_mid); \
     } while (0)
         if (cg == 6) GPSMI_LAUNCH_CORR(6);
@@ -696,21 +701,21 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
     const int span_units = nblocks * ng_span, span_slots = 2 * h->n_cu;
     const int span_per = (span_units + span_slots - 1) / span_slots;
     const dim3 span_grid((span_units + span_per - 1) / (span_per > 0 ? span_per : 1));
-    if (timed && !ext_timed) GPSMI_HIP(hipEventRecord(sl.ev[1], h->stream));
+    if (timed && !ext_timed) GPSMI_HIP(hipEventRecord(sl.ev[1], rs));
     if (h->mfma) {                         // the correlator on the matrix pipe
         const int ng12 = (nch + kSpCh - 1) / kSpCh;
         if (h->mfma == 4 && span_single && u8)
-            hipLaunchKernelGGL((trk_span_kernel<1, 1, 1>), dim3(nblocks * ng12 * 32), dim3(64), 0, h->stream,
+            hipLaunchKernelGGL((trk_span_kernel<1, 1, 1>), dim3(nblocks * ng12 * 32), dim3(64), 0, rs,
                                d_iq_v, sl.d_mid, h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
         else if (h->mfma == 4 && span_single)
-            hipLaunchKernelGGL((trk_span_kernel<1, 1, 0>), dim3(nblocks * ng12 * 32), dim3(64), 0, h->stream,
+            hipLaunchKernelGGL((trk_span_kernel<1, 1, 0>), dim3(nblocks * ng12 * 32), dim3(64), 0, rs,
                                d_iq_v, sl.d_mid, h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
         else if (h->mfma == 4 && ext_timed && u8)
-            hipExtLaunchKernelGGL((trk_span_kernel<8, 4, 1>), span_grid, dim3(256), 0, h->stream,
+            hipExtLaunchKernelGGL((trk_span_kernel<8, 4, 1>), span_grid, dim3(256), 0, rs,
                                   sl.ev[1], sl.ev[2], 0, d_iq_v, (const JobMid*)sl.d_mid,
                                   (const float*)h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
         else if (h->mfma == 4 && ext_timed)
-            hipExtLaunchKernelGGL((trk_span_kernel<8, 4, 0>), span_grid, dim3(256), 0, h->stream,
+            hipExtLaunchKernelGGL((trk_span_kernel<8, 4, 0>), span_grid, dim3(256), 0, rs,
                                   sl.ev[1], sl.ev[2], 0, d_iq_v, (const JobMid*)sl.d_mid,
                                   (const float*)h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
         else if (h->mfma == 4 && side_epilogue && h->done_by_dispatch) {
@@ -718,30 +723,30 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
             // signal of this very dispatch, not a record behind it - a record is one more
             // barrier packet between this kernel and the next batch's first one
             if (u8)
-                hipExtLaunchKernelGGL((trk_span_kernel<8, 4, 1>), span_grid, dim3(256), 0, h->stream,
+                hipExtLaunchKernelGGL((trk_span_kernel<8, 4, 1>), span_grid, dim3(256), 0, rs,
                                       nullptr, sl.corr_done, 0, d_iq_v, (const JobMid*)sl.d_mid,
                                       (const float*)h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
             else
-                hipExtLaunchKernelGGL((trk_span_kernel<8, 4, 0>), span_grid, dim3(256), 0, h->stream,
+                hipExtLaunchKernelGGL((trk_span_kernel<8, 4, 0>), span_grid, dim3(256), 0, rs,
                                       nullptr, sl.corr_done, 0, d_iq_v, (const JobMid*)sl.d_mid,
                                       (const float*)h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
             corr_done_recorded = true;
         } else if (h->mfma == 4 && u8)
-            hipLaunchKernelGGL((trk_span_kernel<8, 4, 1>), span_grid, dim3(256), 0, h->stream,
+            hipLaunchKernelGGL((trk_span_kernel<8, 4, 1>), span_grid, dim3(256), 0, rs,
                                d_iq_v, sl.d_mid, h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
         else
-            hipLaunchKernelGGL((trk_span_kernel<8, 4, 0>), span_grid, dim3(256), 0, h->stream,
+            hipLaunchKernelGGL((trk_span_kernel<8, 4, 0>), span_grid, dim3(256), 0, rs,
                                d_iq_v, sl.d_mid, h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
     } else if (h->span8) {                 // CS = 16368, N_CYC = 8 on the matrix pipe
         const int ng12 = (nch + kSpCh - 1) / kSpCh;
         const int nwaves = nblocks * ng12 * kS8Ranges;
-        hipLaunchKernelGGL(trk_span8_kernel, dim3((nwaves + 3) / 4), dim3(256), 0, h->stream, d_iq,
+        hipLaunchKernelGGL(trk_span8_kernel, dim3((nwaves + 3) / 4), dim3(256), 0, rs, d_iq,
                            sl.d_mid, h->d_code_eo, P, ng12, nblocks, sl.d_rec);
     } else {                               // the vector correlator (other block / code lengths)
         const dim3 grid(sgrid.x, h->nchunks), block(kStreamThreads);
         float2* pdst = h->nchunks > 1 ? h->d_partial_g : sl.d_partial;
 #define GPSMI_LAUNCH_STREAM(NC, POW2, J)                                                        \
-    hipLaunchKernelGGL((trk_stream_kernel<NC, POW2, J>), grid, block, 0, h->stream, d_iq, st_in, \
+    hipLaunchKernelGGL((trk_stream_kernel<NC, POW2, J>), grid, block, 0, rs, d_iq, st_in, \
                        sl.d_mid, h->d_code, P, ngroups, nblocks, pdst)
 #define GPSMI_LAUNCH_STREAM_NC(POW2, J)                 \
     do {                                                \
@@ -756,17 +761,17 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
         if (h->nchunks > 1) {
             const int per_job = P.n_cyc + 1;
             hipLaunchKernelGGL(trk_partial_reduce_kernel, dim3((njobs * per_job + 255) / 256),
-                               dim3(256), 0, h->stream, h->d_partial_g, h->nchunks, per_job, njobs,
+                               dim3(256), 0, rs, h->d_partial_g, h->nchunks, per_job, njobs,
                                sl.d_mid, sl.d_partial);
         }
     }
-    if (timed && !ext_timed) GPSMI_HIP(hipEventRecord(sl.ev[2], h->stream));
+    if (timed && !ext_timed) GPSMI_HIP(hipEventRecord(sl.ev[2], rs));
     // replay: the epilogue goes to a stream of its own behind the correlator, so that the
     // code-phase correlation of the next run (other slot, main stream) starts at once
-    hipStream_t es = h->stream;
+    hipStream_t es = rs;
     if (side_epilogue) {
         es = h->epi_stream;
-        if (!corr_done_recorded) GPSMI_HIP(hipEventRecord(sl.corr_done, h->stream));
+        if (!corr_done_recorded) GPSMI_HIP(hipEventRecord(sl.corr_done, rs));
         h->main_tail = sl.corr_done;          // (gpsmi_acq_after_trk orders the search behind this one)
         GPSMI_HIP(hipStreamWaitEvent(es, sl.corr_done, 0));
     }
@@ -807,6 +812,7 @@ static int trk_take_timing(gpsmi_trk* h, gpsmi_trk::Slot& sl) {
 static int trk_settle(gpsmi_trk* h) {
     if (h->up_stream && (h->stage_used[0] || h->stage_used[1])) GPSMI_HIP(hipStreamSynchronize(h->up_stream));
     GPSMI_HIP(hipStreamSynchronize(h->stream));
+    if (h->alt_stream) GPSMI_HIP(hipStreamSynchronize(h->alt_stream));
     GPSMI_HIP(hipStreamSynchronize(h->epi_stream));
     h->slot[0].epi_pending = h->slot[1].epi_pending = false;
     h->in_pending[0] = h->in_pending[1] = false;
@@ -924,7 +930,8 @@ static int trk_quiesce(gpsmi_trk* h) {
 namespace gpsmi {
 HandleSync trk_sync(gpsmi_trk* h) {
     (void)trk_quiesce(h);                  // (a streamed step still being enqueued belongs in front)
-    return HandleSync{h->stream, h->order, h->cfg.device, h->main_tail};
+    hipStream_t latest = h->slot[h->cur].run_stream ? h->slot[h->cur].run_stream : h->stream;
+    return HandleSync{latest, h->order, h->cfg.device, h->main_tail};
 }
 }  // namespace gpsmi
 
@@ -1109,6 +1116,7 @@ int gpsmi_trk_destroy(gpsmi_trk* h) {
     }
     if (h->up_stream) (void)hipStreamDestroy(h->up_stream);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+    if (h->alt_stream) { (void)hipStreamSynchronize(h->alt_stream); (void)hipStreamDestroy(h->alt_stream); }
     if (h->epi_stream) (void)hipStreamDestroy(h->epi_stream);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1243,6 +1251,7 @@ int gpsmi_trk_process_dev(gpsmi_trk* h, const void* d_iq, size_t n, gpsmi_trk_ou
     }
     gpsmi_trk::Slot& sl = h->slot[0];      // the closed loop needs one slot only
     h->cur = 0;
+    sl.run_stream = nullptr;
     // the streams of a handle are the "blocks" of one launch: stream r reads block r of d_iq and
     // owns the state rows r * max_ch ..., updated in place
     rc = trk_launch(h, sl, d_iq, h->d_state, h->d_state, nullptr, h->rows(), h->max_ch);
@@ -1353,6 +1362,7 @@ static int trk_stream_step(gpsmi_trk* h, const void* iq, size_t n, gpsmi_trk_out
     }
     gpsmi_trk::Slot& sl = h->slot[0];
     h->cur = 0;
+    sl.run_stream = nullptr;
     const bool timing = h->timing;
     h->timing = false;                      // (no kernel-timing events in a streaming loop)
     gpsmi_trk_out* const d_out_keep = sl.d_out;
@@ -1463,16 +1473,24 @@ int gpsmi_trk_replay_run_async(gpsmi_trk* h, const void* d_iq, int nb) {
     const int nch = h->max_ch;
     h->cur ^= 1;                           // the other slot may still be on its way to the host
     gpsmi_trk::Slot& sl = h->slot[h->cur];
+    // "corr_overlap": consecutive runs are independent (two result slots), so they alternate between
+    // two streams: the code-phase correlation of run k + 1 is then eligible while the correlator of
+    // run k still runs, and the chip is never left to one kernel's tail.  Every kernel then shares
+    // CUs with another one: throughput mode; the default keeps each kernel alone (its duration is
+    // what the roofline is quoted on).
+    if (h->corr_overlap && h->cur == 1 && !h->alt_stream) GPSMI_HIP(hipStreamCreate(&h->alt_stream));
+    sl.run_stream = (h->corr_overlap && h->cur == 1) ? h->alt_stream : nullptr;
+    hipStream_t rs = sl.run_stream ? sl.run_stream : h->stream;
     if (sl.copy_pending) {                 // its previous results must have left first
         // (that copy was queued behind the slot's epilogue -- replay_fetch_async -- so it stands for
         // both: one barrier packet between this run's first kernel and the previous run's last
         // instead of two, ~2 us of every step)
-        GPSMI_HIP(hipStreamWaitEvent(h->stream, sl.copied, 0));
+        GPSMI_HIP(hipStreamWaitEvent(rs, sl.copied, 0));
         sl.copy_pending = false;
         sl.epi_pending = false;
     }
     if (sl.epi_pending) {                  // ... or the epilogue that read its buffers be done
-        GPSMI_HIP(hipStreamWaitEvent(h->stream, sl.epi_done, 0));
+        GPSMI_HIP(hipStreamWaitEvent(rs, sl.epi_done, 0));
         sl.epi_pending = false;
     }
     sl.timing_pending = h->timing;
@@ -1532,7 +1550,7 @@ int gpsmi_trk_replay_fetch_async(gpsmi_trk* h, gpsmi_trk_out* out, size_t n) {
     if (sl.epi_pending) {                  // the records are complete when the slot's epilogue is
         GPSMI_HIP(hipStreamWaitEvent(h->copy_stream, sl.epi_done, 0));
     } else {
-        GPSMI_HIP(hipEventRecord(sl.ready, h->stream));
+        GPSMI_HIP(hipEventRecord(sl.ready, sl.run_stream ? sl.run_stream : h->stream));
         GPSMI_HIP(hipStreamWaitEvent(h->copy_stream, sl.ready, 0));
     }
     GPSMI_HIP(hipMemcpyAsync(out, sl.d_out, n * sizeof(gpsmi_trk_out), hipMemcpyDeviceToHost,
