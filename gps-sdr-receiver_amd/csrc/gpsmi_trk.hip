@@ -384,6 +384,7 @@ __global__ __launch_bounds__(256) void trk_epilogue_kernel(
 // loop).  The four waves add up the spans of one quarter each (independent loads, issued
 // together), wave 0 adds the quarters in their fixed order, forms the windows and runs the
 // per-job part.
+template <int NC>
 __global__ __launch_bounds__(256) void trk_epilogue_span_kernel(
     const gpsmi_trk_state* __restrict__ st_in, gpsmi_trk_state* __restrict__ st_out,
     const JobMid* __restrict__ mid, const float* __restrict__ rec, int ng_span, TrkParams P,
@@ -406,8 +407,8 @@ __global__ __launch_bounds__(256) void trk_epilogue_span_kernel(
         if (wave == 0) epilogue_closed(st_in[job], st_out[job], out[job], st_out != st_in, lane);
         return;
     }
-    span_collect_quarter<1>(rec, ng_span, job / P.nch, job % P.nch, md.delay_used, lane, wave,
-                            q_hi[wave][lane], q_lo[wave][lane]);
+    span_collect_quarter<1, NC>(rec, ng_span, job / P.nch, job % P.nch, md.delay_used, lane, wave,
+                                q_hi[wave][lane], q_lo[wave][lane]);
     __syncthreads();
     if (wave != 0) return;
     float h = 0.f, l = 0.f;
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(256) void trk_epilogue_span_kernel(
     s_hi[lane] = h;
     s_lo[lane] = l;
     __builtin_amdgcn_wave_barrier();
-    span_windows(s_hi, s_lo, md.om, lane, s_S);
+    span_windows<NC>(s_hi, s_lo, md.om, lane, s_S);
     __builtin_amdgcn_wave_barrier();
     epilogue_job(s_si, st_out[job], md.delay_used, s_S, P, out[job], lane, s_mag, s_dev, s_real, s_df);
 }
@@ -698,45 +699,46 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
     bool corr_done_recorded = false;
     // batch form of the span correlator: persistent workgroups, two per CU, an equal number of
     // (block, channel group) units each
-    const int span_units = nblocks * ng_span, span_slots = 2 * h->n_cu;
+    const int span_units = nblocks * ng_span, span_slots = (P.n_cyc == 32 ? 2 : 3) * h->n_cu;   // (kSpWgPerCu)
     const int span_per = (span_units + span_slots - 1) / span_slots;
     const dim3 span_grid((span_units + span_per - 1) / (span_per > 0 ? span_per : 1));
     if (timed && !ext_timed) GPSMI_HIP(hipEventRecord(sl.ev[1], rs));
-    if (h->mfma) {                         // the correlator on the matrix pipe
+    if (h->mfma) {                         // the correlator on the matrix pipe (span form, N_CYC = 32 / 16 / 8)
         const int ng12 = (nch + kSpCh - 1) / kSpCh;
-        if (h->mfma == 4 && span_single && u8)
-            hipLaunchKernelGGL((trk_span_kernel<1, 1, 1>), dim3(nblocks * ng12 * 32), dim3(64), 0, rs,
-                               d_iq_v, sl.d_mid, h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
-        else if (h->mfma == 4 && span_single)
-            hipLaunchKernelGGL((trk_span_kernel<1, 1, 0>), dim3(nblocks * ng12 * 32), dim3(64), 0, rs,
-                               d_iq_v, sl.d_mid, h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
-        else if (h->mfma == 4 && ext_timed && u8)
-            hipExtLaunchKernelGGL((trk_span_kernel<8, 4, 1>), span_grid, dim3(256), 0, rs,
-                                  sl.ev[1], sl.ev[2], 0, d_iq_v, (const JobMid*)sl.d_mid,
-                                  (const float*)h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
-        else if (h->mfma == 4 && ext_timed)
-            hipExtLaunchKernelGGL((trk_span_kernel<8, 4, 0>), span_grid, dim3(256), 0, rs,
-                                  sl.ev[1], sl.ev[2], 0, d_iq_v, (const JobMid*)sl.d_mid,
-                                  (const float*)h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
-        else if (h->mfma == 4 && side_epilogue && h->done_by_dispatch) {
-            // replay: the event the epilogue stream (and a search) waits for is the completion
-            // signal of this very dispatch, not a record behind it - a record is one more
-            // barrier packet between this kernel and the next batch's first one
-            if (u8)
-                hipExtLaunchKernelGGL((trk_span_kernel<8, 4, 1>), span_grid, dim3(256), 0, rs,
-                                      nullptr, sl.corr_done, 0, d_iq_v, (const JobMid*)sl.d_mid,
-                                      (const float*)h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
-            else
-                hipExtLaunchKernelGGL((trk_span_kernel<8, 4, 0>), span_grid, dim3(256), 0, rs,
-                                      nullptr, sl.corr_done, 0, d_iq_v, (const JobMid*)sl.d_mid,
-                                      (const float*)h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
-            corr_done_recorded = true;
-        } else if (h->mfma == 4 && u8)
-            hipLaunchKernelGGL((trk_span_kernel<8, 4, 1>), span_grid, dim3(256), 0, rs,
-                               d_iq_v, sl.d_mid, h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
-        else
-            hipLaunchKernelGGL((trk_span_kernel<8, 4, 0>), span_grid, dim3(256), 0, rs,
-                               d_iq_v, sl.d_mid, h->d_code_eo, P, ng12, nblocks, sl.d_rec, sl.d_partial);
+        const JobMid* cmid = sl.d_mid;
+        const float* ceo = h->d_code_eo;
+        // one launch of trk_span_kernel<NSPANS, WAVES, FMT, 0, NC>: with the dispatch's own begin / end
+        // stamps (ext, both events), with its completion signal as `stop` alone, or plainly
+#define GPSMI_LAUNCH_SPAN(NSP, WV, FMTV, NCV, GRID, BLOCK)                                                     \
+    do {                                                                                                      \
+        if (ext_timed && (NSP) == 8)                                                                          \
+            hipExtLaunchKernelGGL((trk_span_kernel<NSP, WV, FMTV, 0, NCV>), GRID, BLOCK, 0, rs, sl.ev[1],     \
+                                  sl.ev[2], 0, d_iq_v, cmid, ceo, P, ng12, nblocks, sl.d_rec, sl.d_partial);  \
+        else if (by_dispatch && (NSP) == 8)                                                                   \
+            hipExtLaunchKernelGGL((trk_span_kernel<NSP, WV, FMTV, 0, NCV>), GRID, BLOCK, 0, rs, nullptr,      \
+                                  sl.corr_done, 0, d_iq_v, cmid, ceo, P, ng12, nblocks, sl.d_rec,             \
+                                  sl.d_partial);                                                              \
+        else                                                                                                  \
+            hipLaunchKernelGGL((trk_span_kernel<NSP, WV, FMTV, 0, NCV>), GRID, BLOCK, 0, rs, d_iq_v, cmid,    \
+                               ceo, P, ng12, nblocks, sl.d_rec, sl.d_partial);                                \
+    } while (0)
+#define GPSMI_LAUNCH_SPAN_NC(NCV)                                                                       \
+    do {                                                                                               \
+        if (span_single && u8) GPSMI_LAUNCH_SPAN(1, 1, 1, NCV, dim3(nblocks * ng12 * 32), dim3(64));   \
+        else if (span_single) GPSMI_LAUNCH_SPAN(1, 1, 0, NCV, dim3(nblocks * ng12 * 32), dim3(64));    \
+        else if (u8) GPSMI_LAUNCH_SPAN(8, 4, 1, NCV, span_grid, dim3(256));                            \
+        else GPSMI_LAUNCH_SPAN(8, 4, 0, NCV, span_grid, dim3(256));                                    \
+    } while (0)
+        // replay: the event the epilogue stream (and a search) waits for is the completion signal of
+        // this very dispatch, not a record behind it - a record is one more barrier packet between
+        // this kernel and the next batch's first one
+        const bool by_dispatch = !ext_timed && !span_single && side_epilogue && h->done_by_dispatch;
+        if (P.n_cyc == 32) GPSMI_LAUNCH_SPAN_NC(32);
+        else if (P.n_cyc == 16) GPSMI_LAUNCH_SPAN_NC(16);
+        else GPSMI_LAUNCH_SPAN_NC(8);
+#undef GPSMI_LAUNCH_SPAN_NC
+#undef GPSMI_LAUNCH_SPAN
+        corr_done_recorded = by_dispatch;
     } else if (h->span8) {                 // CS = 16368, N_CYC = 8 on the matrix pipe
         const int ng12 = (nch + kSpCh - 1) / kSpCh;
         const int nwaves = nblocks * ng12 * kS8Ranges;
@@ -778,8 +780,14 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
     if (h->span8)
         hipLaunchKernelGGL(trk_epilogue_span8_kernel, dim3((njobs + 3) / 4), dim3(256), 0, es, st_in,
                            st_out, sl.d_mid, sl.d_rec, ng_span, P, njobs, sl.d_out);
+    else if (span_single && P.n_cyc == 32)
+        hipLaunchKernelGGL(trk_epilogue_span_kernel<32>, dim3(njobs), dim3(256), 0, es, st_in, st_out,
+                           sl.d_mid, sl.d_rec, ng_span, P, njobs, sl.d_out);
+    else if (span_single && P.n_cyc == 16)
+        hipLaunchKernelGGL(trk_epilogue_span_kernel<16>, dim3(njobs), dim3(256), 0, es, st_in, st_out,
+                           sl.d_mid, sl.d_rec, ng_span, P, njobs, sl.d_out);
     else if (span_single)
-        hipLaunchKernelGGL(trk_epilogue_span_kernel, dim3(njobs), dim3(256), 0, es, st_in, st_out,
+        hipLaunchKernelGGL(trk_epilogue_span_kernel<8>, dim3(njobs), dim3(256), 0, es, st_in, st_out,
                            sl.d_mid, sl.d_rec, ng_span, P, njobs, sl.d_out);
     else
         hipLaunchKernelGGL(trk_epilogue_kernel, dim3((njobs + 3) / 4), dim3(256), 0, es, st_in,
@@ -1000,7 +1008,7 @@ static int trk_build(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk* h) {
     {
         // default for CS = 2048, N_CYC = 32: the span form of the MFMA correlator.  One form per handle:
         // the closed loop and the replay of a handle sum in the same order (bytewise equal results).
-        h->mfma = (!h->general && cfg->n_cyc == 32 && want_matrix != 0) ? 4 : 0;
+        h->mfma = (!h->general && want_matrix != 0) ? 4 : 0;          // (N_CYC = 32, 16 and 8: template parameter NC)
         if (h->mfma) {
             const size_t b2 = (size_t)(GPSMI_MAX_PRN + 1) * 2 * kFftN * sizeof(float);
             GPSMI_HIP(hipMalloc((void**)&h->d_code_eo, b2));
@@ -1617,8 +1625,8 @@ int gpsmi_trk_set_input_format(gpsmi_trk* h, int fmt) {
     GPSMI_QUIESCE(h);
     GPSMI_REQUIRE(fmt == GPSMI_IQ_C64 || fmt == GPSMI_IQ_U8, "unknown input format");
     if (fmt == GPSMI_IQ_U8 && h->mfma != 4)
-        return fail(GPSMI_E_UNSUPPORTED, "raw u8 IQ input needs CODE_SAMPLES = 2048, N_CYC = 32 "
-                                         "(the span correlator)");
+        return fail(GPSMI_E_UNSUPPORTED, "raw u8 IQ input needs CODE_SAMPLES = 2048 and the span "
+                                         "correlator (option \"correlator\" = 1)");
     h->iq_fmt = fmt;
     return GPSMI_OK;
 }

@@ -1,4 +1,5 @@
-// The tracking correlator, span form (default for CS = 2048, N_CYC = 32).
+// The tracking correlator, span form (default for CS = 2048; N_CYC = 32, and -- round 4 -- 16 and 8:
+// template parameter NC, one M tile of 16 rows instead of two, see "Other block lengths" below).
 //
 // Same mathematics as gpsmi_trk_stream_mfma.h -- prompt correlate-and-dump of a 32-ms
 // block, y = roll(replica, delay) * (data * exp(-j(phase + 2 pi f t))) summed per
@@ -48,6 +49,14 @@
 // latency under load), so nothing outside the tile loop may wait for a global load: see the
 // comments at sp_swap_tile, in span_wave (where the replica entries are requested) and at the
 // batch form of the kernel (scalar descriptor fetch, LDS-only barriers, lo sums parked in LDS).
+//
+// Other block lengths (gpsglob.py:122-124: N_CYC "currently possible are (32,16,8)").  NC = 16 is ONE M
+// tile (MT = 1) of the same scheme: tiles of 16 rows x 64 positions (8 KiB, eight loads per lane), half the
+// MFMAs per tile and the same B arithmetic, 168 VGPRs -> three workgroups per CU.  NC = 8 runs the same
+// code with half of the M tile empty (rows 8..15 of A are whatever the tile area holds: row r of D depends
+// on row r of A alone and nobody reads those rows); it beats the vector kernel (23 % of the HBM peak) by
+// a little and shares every line with the other two.  The summation order is unchanged, so the
+// single-block form and the batch form stay bytewise equal for every NC.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -130,16 +139,16 @@ __device__ __forceinline__ SpDesc sp_desc(const JobMid* __restrict__ midrow, int
 // FMT 1: the block is raw uint16 (Q << 8 | I) samples as the recorder writes them
 // (gpsrecv.py:168-173), 2 bytes per sample: four instructions per tile, instruction i covers
 // rows 8 i + lane / 8 and 128 bytes (64 samples) of each; sp_store_tile decodes them.
-template <int AUX = 2, int FMT = 0>
+template <int AUX = 2, int FMT = 0, int NC = 32>
 __device__ __forceinline__ void sp_load_tile(const void* blk, int pos, int lane, sp4 (&st)[16]) {
-    constexpr int CS = kFftN, NC = 32;
+    constexpr int CS = kFftN;
     if (FMT == 0) {
         const __amdgpu_buffer_rsrc_t blk_rs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<void*>(blk), 0, CS * NC * (int)sizeof(float2), kRsrcFlags);
         const int ld_off = ((lane >> 5) * CS + 2 * (lane & 31)) * (int)sizeof(float2);
         const int tb = pos * (int)sizeof(float2);
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
+        for (int i = 0; i < NC / 2; ++i)
             st[i] = __builtin_bit_cast(sp4, __builtin_amdgcn_raw_buffer_load_b128(
                 blk_rs, ld_off, tb + i * (2 * CS * (int)sizeof(float2)), AUX));
     } else {
@@ -148,14 +157,14 @@ __device__ __forceinline__ void sp_load_tile(const void* blk, int pos, int lane,
         const int ld_off = ((lane >> 3) * CS + 8 * (lane & 7)) * 2;
         const int tb = pos * 2;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NC / 8; ++i)
             st[i] = __builtin_bit_cast(sp4, __builtin_amdgcn_raw_buffer_load_b128(
                 blk_rs, ld_off, tb + i * (8 * CS * 2), AUX));
     }
 }
 // the staged tile into LDS (interleaved re / im, row pitch kSpRowDw); FMT 1 decodes the raw
 // samples exactly as gpsmi_dev_unpack_u8iq does: fl32(byte) * fl32(1 / 127.5) - 1, two roundings
-template <int FMT>
+template <int FMT, int NC = 32>
 __device__ __forceinline__ void sp_store_tile(float* tl, int lane, const sp4 (&st)[16]) {
     if (FMT == 0) {
         // rows are 8-byte aligned (pitch 130 dwords, which the transposed reads need): two b64 writes
@@ -169,7 +178,7 @@ __device__ __forceinline__ void sp_store_tile(float* tl, int lane, const sp4 (&s
         float* d0 = st_dst + 2 * swz;                  // where the piece's first sample goes
         float* d1 = st_dst + 2 * (1 - swz);            // ... and its second
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < NC / 2; ++i) {
             *reinterpret_cast<sp2*>(d0 + i * 2 * kSpRowDw) = sp2{st[i].x, st[i].y};
             *reinterpret_cast<sp2*>(d1 + i * 2 * kSpRowDw) = sp2{st[i].z, st[i].w};
         }
@@ -177,7 +186,7 @@ __device__ __forceinline__ void sp_store_tile(float* tl, int lane, const sp4 (&s
         float* st_dst = tl + (lane >> 3) * kSpRowDw + 16 * (lane & 7);
         const float scl = 1.0f / 127.5f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NC / 8; ++i) {
             // (the whole vector is reinterpreted at once: with hipcc 7.2 a per-element
             // __builtin_bit_cast(unsigned, st[i][w]) made the compiler narrow the 16-byte load
             // to its first dword and use that for all four)
@@ -200,9 +209,9 @@ __device__ __forceinline__ void sp_store_tile(float* tl, int lane, const sp4 (&s
 // asked for again as soon as it has been written to LDS, so a wave's requests never drain to zero
 // while it waits for the last rows of a tile and stores them (loads return in order: the wait in
 // front of piece i lets the 15 requests behind it stay in flight).
-template <int AUX, int FMT>
+template <int AUX, int FMT, int NC = 32>
 __device__ __forceinline__ void sp_swap_tile(float* tl, int lane, sp4 (&st)[16], const void* blk, int pos) {
-    constexpr int CS = kFftN, NC = 32;
+    constexpr int CS = kFftN;
     if (FMT == 0) {
         const __amdgpu_buffer_rsrc_t blk_rs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<void*>(blk), 0, CS * NC * (int)sizeof(float2), kRsrcFlags);
@@ -213,7 +222,7 @@ __device__ __forceinline__ void sp_swap_tile(float* tl, int lane, sp4 (&st)[16],
         float* d0 = st_dst + 2 * swz;
         float* d1 = st_dst + 2 * (1 - swz);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < NC / 2; ++i) {
             *reinterpret_cast<sp2*>(d0 + i * 2 * kSpRowDw) = sp2{st[i].x, st[i].y};
             *reinterpret_cast<sp2*>(d1 + i * 2 * kSpRowDw) = sp2{st[i].z, st[i].w};
             __builtin_amdgcn_sched_barrier(0);
@@ -222,8 +231,8 @@ __device__ __forceinline__ void sp_swap_tile(float* tl, int lane, sp4 (&st)[16],
             __builtin_amdgcn_sched_barrier(0);
         }
     } else {
-        sp_store_tile<FMT>(tl, lane, st);
-        sp_load_tile<AUX, FMT>(blk, pos, lane, st);
+        sp_store_tile<FMT, NC>(tl, lane, st);
+        sp_load_tile<AUX, FMT, NC>(blk, pos, lane, st);
     }
 }
 
@@ -289,13 +298,14 @@ __device__ __forceinline__ void sp_rec3(sp2 nk, sp2& u1, sp2& d1, sp2& u2, sp2& 
 // tile's store / request sequence: the place for loads that must not wait behind rows.
 // (DIAG: tools/probe/span_prof.hip only -- 1 no MFMAs, 2 no row loads after the first tile, 8 default
 // cache policy; the library instantiates DIAG = 0 alone, where every test of it folds away)
-template <int NSPANS, int FMT = 0, int DIAG = 0, class Close, class Hook>
+template <int NSPANS, int FMT = 0, int DIAG = 0, int NC = 32, class Close, class Hook>
 __device__ __forceinline__ void span_wave(const void* __restrict__ blk, const void* next_blk,
                                           int next_pos, float* tl, const SpDesc& cmd,
                                           const float* __restrict__ code_q4, int pos0, int lane,
-                                          sp4 (&st)[16], sp4 (&tot)[2][2], bool& all_lo, int& pb,
+                                          sp4 (&st)[16], sp4 (&tot)[(NC + 15) / 16][2], bool& all_lo, int& pb,
                                           Close&& close, Hook&& after_first_swap) {
     constexpr int CS = kFftN;
+    constexpr int MT = (NC + 15) / 16;                           // M tiles of 16 rows
     const int k = lane >> 4;
     const int q0 = pos0 & ~(kSpQuarter - 1);                      // start of the quarter
     constexpr int kTiles = NSPANS;
@@ -361,16 +371,16 @@ __device__ __forceinline__ void span_wave(const void* __restrict__ blk, const vo
     load_half(0, cd[0], cd[1]);
 
     const sp4 zero4 = sp4{0.f, 0.f, 0.f, 0.f};
-    sp4 k1[2], k2[2], k3[2];                             // the three products per M tile
+    sp4 k1[MT], k2[MT], k3[MT];                          // the three products per M tile
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
         k1[mt] = zero4; k2[mt] = zero4; k3[mt] = zero4;
         tot[mt][0] = zero4; tot[mt][1] = zero4;
     }
     // the lanes of a channel close its lo sum where the boundary passes
     auto close_lo = [&]() {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
             close(mt, tot[mt][0] + (k1[mt] - k3[mt]), tot[mt][1] + (k1[mt] + k2[mt]));
             tot[mt][0] = zero4; tot[mt][1] = zero4;
             k1[mt] = zero4; k2[mt] = zero4; k3[mt] = zero4;
@@ -396,17 +406,17 @@ __device__ __forceinline__ void span_wave(const void* __restrict__ blk, const vo
     const int swz_ofs = FMT == 0 ? ((k & 1) ? -2 : 2) : 0;
 
     // operands of one K-step (four positions): the lane's sample of both row halves and re + im
-    struct Ops { sp2 x[2]; float xs[2]; };
+    struct Ops { sp2 x[MT]; float xs[MT]; };
     auto read_ops = [&](int s) {                                     // s: K-step index in the tile
         Ops o;
         const float* p = ap + (((s >> 2) & 1) ? swz_ofs : 0) + 8 * s;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) o.x[mt] = *reinterpret_cast<const sp2*>(p + mt * 16 * kSpRowDw);
+        for (int mt = 0; mt < MT; ++mt) o.x[mt] = *reinterpret_cast<const sp2*>(p + mt * 16 * kSpRowDw);
         return o;
     };
     auto sums = [&](Ops& o) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) o.xs[mt] = o.x[mt].x + o.x[mt].y;
+        for (int mt = 0; mt < MT; ++mt) o.xs[mt] = o.x[mt].x + o.x[mt].y;
     };
     auto mfma = [&](float a, float b, sp4 c) -> sp4 {
         if (DIAG & 1) { c[0] = fmaf(a, b, c[0]); return c; }
@@ -415,7 +425,7 @@ __device__ __forceinline__ void span_wave(const void* __restrict__ blk, const vo
     // one K-step: six MFMAs (first: C = 0, an inline constant, no zeroing of the accumulators)
     auto kstep = [&](const Ops& o, float b1, float b2, float b3, auto first) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
             k1[mt] = mfma(o.xs[mt], b1, decltype(first)::value ? zero4 : k1[mt]);
             k2[mt] = mfma(o.x[mt].x, b2, decltype(first)::value ? zero4 : k2[mt]);
             k3[mt] = mfma(o.x[mt].y, b3, decltype(first)::value ? zero4 : k3[mt]);
@@ -432,10 +442,10 @@ __device__ __forceinline__ void span_wave(const void* __restrict__ blk, const vo
         if (t + 1 < kTiles) load_half(2 * t + 2, cdn[0], cdn[1]);    // (the next RANGE fetches its own)
         if (!(DIAG & 2)) {
             const bool more = t + 1 < kTiles;              // else: the first tile of the wave's next range
-            sp_swap_tile<(DIAG & 8) ? 0 : 2, FMT>(tl, lane, st, more ? blk : next_blk,
-                                                  more ? pos0 + (t + 1) * kSpTile : next_pos);
+            sp_swap_tile<(DIAG & 8) ? 0 : 2, FMT, NC>(tl, lane, st, more ? blk : next_blk,
+                                                      more ? pos0 + (t + 1) * kSpTile : next_pos);
         } else {
-            sp_store_tile<FMT>(tl, lane, st);
+            sp_store_tile<FMT, NC>(tl, lane, st);
         }
     };
     enter_tile(0);
@@ -474,7 +484,7 @@ __device__ __forceinline__ void span_wave(const void* __restrict__ blk, const vo
             const bool fast = nb >= tpos + (hw + 1) * (kSpTile / 2);
             if (!fast && decltype(first)::value) {     // (the accumulators are read where a boundary closes)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) { k1[mt] = zero4; k2[mt] = zero4; k3[mt] = zero4; }
+                for (int mt = 0; mt < MT; ++mt) { k1[mt] = zero4; k2[mt] = zero4; k3[mt] = zero4; }
             }
             Ops o[2];
             o[0] = read_ops(8 * hw);
@@ -516,7 +526,7 @@ __device__ __forceinline__ void span_wave(const void* __restrict__ blk, const vo
         half_tile(1, std::false_type{});
         // a span ends (its accumulators restart from C = 0 at the next span)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
             tot[mt][0] = tot[mt][0] + (k1[mt] - k3[mt]);
             tot[mt][1] = tot[mt][1] + (k1[mt] + k2[mt]);
         }
@@ -558,19 +568,25 @@ constexpr int kSpRecFloats = 2 * 16 * 64;              // one wave's record
 constexpr int kSpLoOfs = 16 * 64;                      // lo_fin within it
 
 // (FMT 1: iq holds raw uint16 samples, 2 bytes each, decoded on the way into LDS)
-template <int NSPANS, int WAVES, int FMT = 0, int DIAG = 0>
-__global__ __launch_bounds__(64 * WAVES, 2) void trk_span_kernel(
+// workgroups per CU the registers admit: two M tiles = 250 VGPRs, one = 168
+template <int NC> constexpr int kSpWgPerCu = NC == 32 ? 2 : 3;
+// a wave's tile area: NC rows (16 at least: the A operand's lanes address rows 0..15)
+template <int NC> constexpr int kSpAreaFloats = (NC < 16 ? 16 : NC) * kSpRowDw;
+
+template <int NSPANS, int WAVES, int FMT = 0, int DIAG = 0, int NC = 32>
+__global__ __launch_bounds__(64 * WAVES, kSpWgPerCu<NC>) void trk_span_kernel(
     const void* __restrict__ iq_v, const JobMid* __restrict__ mid,
     const float* __restrict__ code_eo, TrkParams P, int ngroups, int nblocks,
     float* __restrict__ rec, float2* __restrict__ partial) {
-    constexpr int NC = 32, CS = kFftN;
+    constexpr int CS = kFftN;
+    constexpr int MT = (NC + 15) / 16;
     constexpr int kRanges = CS / (NSPANS * kSpTile);    // per block: 4 quarters or 32 spans
     constexpr bool kWholeBlock = kRanges == WAVES;      // the workgroup holds all ranges of its block
     static_assert(kRanges % WAVES == 0, "the waves of a workgroup share a block");
     constexpr int kNowhere = CS * NC;                   // a tile position past the block: reads nothing
     constexpr size_t kBlkBytes = (size_t)CS * NC * (FMT == 0 ? sizeof(float2) : 2);
     const char* iq = static_cast<const char*>(iq_v);
-    __shared__ __attribute__((aligned(16))) float lds[WAVES][kSpWaveFloats];
+    __shared__ __attribute__((aligned(16))) float lds[WAVES][kSpAreaFloats<NC>];
     __shared__ float4 ufac[kWholeBlock ? kSpCh * (NC + 1) : 1];      // (U[q], U[q+1]); .w = NaN: channel closed
     __shared__ __attribute__((aligned(16))) float lo_close[kWholeBlock ? kSpCh * NC * 2 : 2];   // [channel][row][re, im]
     __shared__ JobMid mids[2][kWholeBlock ? kSpCh : 1];             // descriptors of this unit and the next
@@ -578,7 +594,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void trk_span_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nunits = nblocks * ngroups;
     float* tl = &lds[wave][0];
-    sp4 st[16], tot[2][2];           // [M tile][re, im] of channel lane % 16
+    sp4 st[16], tot[MT][2];          // [M tile][re, im] of channel lane % 16
     bool all_lo;
     int pb;
     SpDesc cmd;
@@ -591,19 +607,19 @@ __global__ __launch_bounds__(64 * WAVES, 2) void trk_span_kernel(
         const int g = unit % ngroups, b = unit / ngroups;
         const char* blk = iq + (size_t)b * kBlkBytes;
         const int pos0 = range * NSPANS * kSpTile;
-        sp_load_tile<(DIAG & 8) ? 0 : 2, FMT>(blk, pos0, lane, st);   // before anything that depends on the descriptors
+        sp_load_tile<(DIAG & 8) ? 0 : 2, FMT, NC>(blk, pos0, lane, st);   // before anything that depends on the descriptors
         float* o = rec + ((size_t)unit * kRanges + range) * kSpRecFloats + lane;
         const int rel0 = pos0 & (kSpQuarter - 1);
         sp_wave_desc(mid + (size_t)b * P.nch + g * kSpCh, P.nch - g * kSpCh, lane, cmd);
-        sp4 lo_fin[2][2];                // what was summed below a boundary inside the span
+        sp4 lo_fin[MT][2];               // what was summed below a boundary inside the span
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) { lo_fin[mt][0] = sp4{0.f, 0.f, 0.f, 0.f}; lo_fin[mt][1] = lo_fin[mt][0]; }
-        span_wave<NSPANS, FMT, DIAG>(blk, blk, kNowhere, tl, cmd, code_eo, pos0, lane, st, tot, all_lo, pb,
-                                     [&](int mt, sp4 re, sp4 im) { lo_fin[mt][0] = re; lo_fin[mt][1] = im; }, [] {});
+        for (int mt = 0; mt < MT; ++mt) { lo_fin[mt][0] = sp4{0.f, 0.f, 0.f, 0.f}; lo_fin[mt][1] = lo_fin[mt][0]; }
+        span_wave<NSPANS, FMT, DIAG, NC>(blk, blk, kNowhere, tl, cmd, code_eo, pos0, lane, st, tot, all_lo, pb,
+                                         [&](int mt, sp4 re, sp4 im) { lo_fin[mt][0] = re; lo_fin[mt][1] = im; }, [] {});
         // rec[unit][span][tot | lo_fin][M tile][re, im][v][lane = 16 (row group) + channel]
         const bool closed = pb > rel0 && pb < rel0 + NSPANS * kSpTile;   // lo was closed in this range
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int p = 0; p < 2; ++p)
 #pragma unroll
@@ -625,7 +641,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void trk_span_kernel(
     // below a boundary go to LDS where the boundary passes (no registers held for them: no spills);
     // the two barriers of the combine step order LDS traffic only.
     constexpr int kSumFloats = kSpCh * NC * 2;          // [channel][row][re, im]
-    static_assert(2 * kSumFloats <= kSpTileFloats, "row sums must fit the tile area");
+    static_assert(2 * kSumFloats <= kSpAreaFloats<NC>, "row sums must fit the tile area");
     constexpr int kItems = (kSpCh * (NC + 1) + 64 * WAVES - 1) / (64 * WAVES);
     int unit = blockIdx.x;
     if (unit >= nunits) return;
@@ -662,7 +678,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void trk_span_kernel(
         }
     };
     {
-        sp_load_tile<(DIAG & 8) ? 0 : 2, FMT>(iq + (size_t)(unit / ngroups) * kBlkBytes, pos0, lane, st);
+        sp_load_tile<(DIAG & 8) ? 0 : 2, FMT, NC>(iq + (size_t)(unit / ngroups) * kBlkBytes, pos0, lane, st);
         for (int i = threadIdx.x; i < kSumFloats; i += 64 * WAVES) lo_close[i] = 0.f;
         park_mids(unit, 0, lane);
         __syncthreads();
@@ -701,9 +717,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void trk_span_kernel(
         __builtin_amdgcn_s_setprio(0);
         const char* blk = iq + (size_t)b * kBlkBytes;
         const char* next_blk = has_next ? iq + (size_t)(next / ngroups) * kBlkBytes : blk;
-        span_wave<NSPANS, FMT, DIAG>(
+        span_wave<NSPANS, FMT, DIAG, NC>(
             blk, next_blk, has_next ? pos0 : kNowhere, tl, cmd, code_eo, pos0, lane_u, st, tot, all_lo, pb,
             [&](int mt, sp4 re, sp4 im) {              // below a boundary: rows 16 mt + 4 (lane / 16) + v of the channel
+                if (NC < 16 && 4 * (lane_u >> 4) >= NC) return;        // (rows the block does not have)
                 float* dst = lo_close + ((lane_u & 15) * NC + 16 * mt + 4 * (lane_u >> 4)) * 2;
 #pragma unroll
                 for (int v = 0; v < 4; ++v) *reinterpret_cast<sp2*>(dst + 2 * v) = sp2{re[v], im[v]};
@@ -718,9 +735,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void trk_span_kernel(
             float* hi = tl;
             float* lo = tl + kSumFloats;
             const int c = lane & 15;
-            if (c < kSpCh) {
+            if (c < kSpCh && (NC >= 16 || 4 * (lane >> 4) < NC)) {
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
                         const int row = 16 * mt + 4 * (lane >> 4) + v;
@@ -761,8 +778,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void trk_span_kernel(
             }
         }
         if (DIAG & 4) {                                  // (probe: keep the sums alive without the combine step)
-            if (tot[0][0][0] + tot[0][1][1] + tot[1][0][2] + tot[1][1][3] == 123.456f)
-                partial[(size_t)unit * 64 + lane] = make_float2(tot[0][0][0], tot[1][1][1]);
+            if (tot[0][0][0] + tot[0][1][1] + tot[MT - 1][0][2] + tot[MT - 1][1][3] == 123.456f)
+                partial[(size_t)unit * 64 + lane] = make_float2(tot[0][0][0], tot[MT - 1][1][1]);
         }
         SPAN_STAMP(5);
         if (!has_next) break;
@@ -775,10 +792,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void trk_span_kernel(
 // The sums of quarter Q of channel `cidx` of block `b`, for lane = (row, re/im): what the
 // quarter contributes to the hi and to the lo side of the delay `d`.  NSPANS = spans per record,
 // as the kernel that wrote them.  (Loads first, then the adds in the fixed order.)
-template <int NSPANS>
+template <int NSPANS, int NC = 32>
 __device__ __forceinline__ void span_collect_quarter(const float* __restrict__ rec, int ngroups, int b,
                                                      int cidx, int d, int lane, int Q, float& w_hi,
                                                      float& w_lo) {
+    if (lane >= 2 * NC) {                 // (row, re/im) pairs the block does not have
+        w_hi = w_lo = 0.f;
+        return;
+    }
     constexpr int kPerQ = kSpQuarter / (NSPANS * kSpTile);   // records per quarter: 1 or 8
     constexpr int kLen = NSPANS * kSpTile;                   // positions per record
     const int g = cidx / kSpCh, cc = cidx % kSpCh;
@@ -815,8 +836,8 @@ __device__ __forceinline__ void span_collect_quarter(const float* __restrict__ r
 
 // hi / lo (64 floats of LDS each, lane = (row, re/im)) -> S[0 .. 32] = what the other
 // correlators write to partial[job][.]; one wave
+template <int NC = 32>
 __device__ __forceinline__ void span_windows(const float* hi, const float* lo, float om, int lane, float2* S) {
-    constexpr int NC = 32;
     if (lane <= NC) {
         const int q = lane - 1;
         const float hx = q >= 0 ? hi[2 * q] : 0.f, hy = q >= 0 ? hi[2 * q + 1] : 0.f;
@@ -826,21 +847,21 @@ __device__ __forceinline__ void span_windows(const float* hi, const float* lo, f
 }
 
 // One wave per job: the four quarters in turn, then the windows.
-template <int NSPANS>
+template <int NSPANS, int NC = 32>
 __device__ __forceinline__ void span_collect(const float* __restrict__ rec, int ngroups, int b, int cidx,
                                              int d, float om, int lane, float* hi, float* lo, float2* S) {
     float h = 0.f, l = 0.f;
 #pragma unroll
     for (int Q = 0; Q < 4; ++Q) {
         float wh, wl;
-        span_collect_quarter<NSPANS>(rec, ngroups, b, cidx, d, lane, Q, wh, wl);
+        span_collect_quarter<NSPANS, NC>(rec, ngroups, b, cidx, d, lane, Q, wh, wl);
         h += wh;
         l += wl;
     }
     hi[lane] = h;
     lo[lane] = l;
     __builtin_amdgcn_wave_barrier();
-    span_windows(hi, lo, om, lane, S);
+    span_windows<NC>(hi, lo, om, lane, S);
     __builtin_amdgcn_wave_barrier();
 }
 

@@ -447,23 +447,38 @@ def test_search_ordered_behind_replay_batches(closed_loop):
 def test_other_block_lengths_match_the_oracle(n_cyc):
     """N_CYC = 16 and 8 at CODE_SAMPLES = 2048 (gpsglob.py:122 allows 8/16/32): no
     fixture from the reference holds these, so the GPU is compared with the oracle
-    (itself bit-exact against the reference at N_CYC = 32 and 8) on a fresh scene."""
+    (itself bit-exact against the reference at N_CYC = 32 and 8) on a fresh scene.  Round 4: these
+    block lengths run the span correlator too (template parameter NC of gpsmi_trk_span.h); the
+    closed loop takes its one-wave-per-span form, the replay of the recorded trajectory its batch
+    form: bytewise equal, complex64 and raw uint16 input alike."""
     import gps_oracle as orc
     from gpsmi import synth
-    from gpsmi.engine import Config, TrkEngine, dumps_of
+    from gpsmi.engine import Config, TrkEngine, DeviceBuffer, STATE_DTYPE, dumps_of
     p = orc.Params(n_cyc=n_cyc)
     sc = synth.default_scene(5, seed=31 + n_cyc, n_cyc=n_cyc, amp=0.09)
     nb = 12 * 32 // n_cyc
     blocks = [sc.block(b) for b in range(nb)]
+    raws = [sc.block_raw(b) for b in range(nb)]
     eng = TrkEngine(Config(n_cyc=n_cyc), max_ch=len(sc.sats))
+    assert eng.get_option('correlator') == 1                  # the matrix-pipe (span) form
+    eng8 = TrkEngine(Config(n_cyc=n_cyc), max_ch=len(sc.sats))
+    eng8.set_input_format(True)
     streams = []
     for c, s in enumerate(sc.sats):
         f0 = round(s.doppler / 200.0) * 200.0
         d0 = int(round(s.delay)) % 2048
         eng.open(c, s.prn, f0, d0)
+        eng8.open(c, s.prn, f0, d0)
         streams.append(orc.SatStream(s.prn, f0, p, delay=d0))
+    nch = len(sc.sats)
+    states = np.zeros((nb, nch), dtype=STATE_DTYPE)
+    outs = []
     for i, blk in enumerate(blocks):
+        for c in range(nch):
+            states[i, c] = eng.get_state(c)
         out = eng.process(blk)
+        outs.append(out)
+        assert eng8.process(raws[i]).tobytes() == out.tobytes(), f'raw u8 input, block {i}'
         for c, ss in enumerate(streams):
             ss.process(blk, np.int64((i + 1) * p.ngps))
             where = f'n_cyc {n_cyc} channel {c} block {i}'
@@ -474,7 +489,79 @@ def test_other_block_lengths_match_the_oracle(n_cyc):
                                        atol=1e-5, err_msg=where)
             assert abs(out[c]['freq'] - ss.freq) < 0.05, where
             assert bool(out[c]['phase_locked']) == bool(ss.phase_locked), where
+    outs = np.stack(outs)
+    # replay of the trajectory: enough blocks that the launch takes the batch form of the correlator
+    reps = 4
+    nbig = nb * reps
+    buf = DeviceBuffer(nbig * blocks[0].nbytes)
+    buf8 = DeviceBuffer(nbig * raws[0].nbytes)
+    for r in range(reps):
+        for i in range(nb):
+            buf.upload(blocks[i], (r * nb + i) * blocks[0].nbytes)
+            buf8.upload(raws[i], (r * nb + i) * raws[0].nbytes)
+    table = np.concatenate([states] * reps)
+    forced = np.concatenate([outs['delay_used']] * reps)
+    assert nbig * 1 > eng.get_option('span_single_max')
+    rep = eng.replay(buf.ptr, nbig, table, forced)
+    rep8 = eng8.replay(buf8.ptr, nbig, table, forced)
+    for r in range(reps):
+        assert rep[r * nb:(r + 1) * nb].tobytes() == outs.tobytes(), r
+        assert rep8[r * nb:(r + 1) * nb].tobytes() == outs.tobytes(), r
+    buf.free()
+    buf8.free()
     eng.close()
+    eng8.close()
+
+
+@pytest.mark.parametrize('n_cyc', [16, 8])
+def test_other_block_lengths_forced_delays_agree_with_the_vector_correlator(n_cyc):
+    """Every residue mod 4 and every tile / quarter / period edge of the delay through the span
+    correlator at N_CYC = 16 / 8 (batch form == single form bytewise), and against the vector
+    correlator (an independent kernel) within the reference tolerance."""
+    from gpsmi import engine as E
+    from gpsmi import synth
+    from gpsmi.engine import Config, TrkEngine, DeviceBuffer, STATE_DTYPE
+    sc = synth.default_scene(12, seed=5 + n_cyc, n_cyc=n_cyc, amp=0.09)
+    nch, nb = 12, 120
+    blocks = [sc.block(b % 6) for b in range(nb)]
+    edges = [0, 1, 2, 3, 4, 5, 6, 7, 61, 62, 63, 64, 65, 66, 67, 127, 128, 129, 130, 131, 255, 256, 257,
+             509, 510, 511, 512, 513, 514, 515, 1021, 1022, 1023, 1024, 1025, 1026, 1027, 1535, 1536, 1537,
+             2040, 2041, 2042, 2043, 2044, 2045, 2046, 2047]
+    eng = TrkEngine(Config(n_cyc=n_cyc), max_ch=nch)
+    for c, s in enumerate(sc.sats):
+        eng.open(c, s.prn, round(s.doppler / 200.0) * 200.0, int(round(s.delay)) % 2048)
+    st0 = np.array([eng.get_state(c) for c in range(nch)], dtype=STATE_DTYPE)
+    table = np.broadcast_to(st0, (nb, nch)).copy()
+    rng = np.random.default_rng(3)
+    table['phase'] = rng.uniform(0, 6.28, (nb, nch)).astype(np.float32)
+    forced = np.empty((nb, nch), dtype=np.int32)
+    for i in range(nb):
+        for c in range(nch):
+            k = i * nch + c
+            forced[i, c] = (int(round(sc.sats[c].delay)) + int(rng.integers(-3, 4))) % 2048 if k % 3 == 0 \
+                else edges[(k // 3 + 7 * c) % len(edges)]
+    buf = DeviceBuffer(nb * blocks[0].nbytes)
+    for i in range(nb):
+        buf.upload(blocks[i], i * blocks[0].nbytes)
+    whole = eng.replay(buf.ptr, nb, table, forced)                       # batch form
+    pieces = np.concatenate([eng.replay(buf.at(i * blocks[0].nbytes), 4, table[i:i + 4], forced[i:i + 4])
+                             for i in range(0, nb, 4)])                  # single form
+    assert pieces.tobytes() == whole.tobytes()
+    eng.close()
+    E.set_default('correlator', 0)
+    try:
+        veng = TrkEngine(Config(n_cyc=n_cyc), max_ch=nch)
+    finally:
+        E.clear_default('correlator')
+    assert veng.get_option('correlator') == 0
+    for c, s in enumerate(sc.sats):
+        veng.open(c, s.prn, 0.0, 0)
+    vec = veng.replay(buf.ptr, nb, table, forced)
+    veng.close()
+    buf.free()
+    for k in ('mx', 'delay', 'delay_used', 'n_dumps', 'nps', 'first_len'):
+        assert np.array_equal(vec[k], whole[k]), k
+    np.testing.assert_allclose(vec['dumps'], whole['dumps'], rtol=1e-3, atol=5e-4)
 
 
 @pytest.mark.parametrize('corr_avg', [4, 5, 12])
