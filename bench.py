@@ -75,19 +75,45 @@ HBM_COPY_GBS = 6290.0          # same guide: measured float4 copy
 SEED = 7
 TIMED_EVERY = 4                # steps between two kernel-timed steps
 N_CH = 12
-PMC_FILE = os.path.join('profiles', 'round3', 'pmc_counters.txt')
+PMC_FILE = os.path.join('profiles', 'round4', 'pmc_counters.txt')
 ISSUE_CYCLES = 4.9             # measured cycles per packed-fp32 VALU instruction of one wave's stream
                                # (tools/probe/hazard_probe.hip); the FFT kernels are made of those
 ISSUE_CLOCK_GHZ = 2.2          # the clock DESIGN section 4.4 priced its 78 us floor at
 
 
+def csrc_sha256():
+    """sha256 over the kernel sources (csrc/*.h, *.hip in name order): what ties a committed
+    counter summary to the code it was taken from (tools/pmc_summary.py --stamp writes it)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'gps-sdr-receiver_amd', 'csrc')
+    for f in sorted(glob.glob(os.path.join(d, '*.h')) + glob.glob(os.path.join(d, '*.hip'))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()
+
+
+def pmc_matches_sources():
+    """True when the committed counter summary names the present kernel sources."""
+    try:
+        first = open(os.path.join(ROOT, PMC_FILE)).readline()
+    except OSError:
+        return False
+    return first.startswith('# csrc_sha256 ') and first.split()[2] == csrc_sha256()
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc pass of
-    tools/kernel_bench.py at this HEAD (same kernel, same batch; separate counter
-    passes): FETCH_SIZE counts KiB and on gfx950 reports half of a wide coalesced read
-    stream (MI355X_MICROARCH.md, HBM), WRITE_SIZE is exact.  (None, None) if absent:
-    this is NOT a measurement of the present run and is labelled as such."""
+    tools/kernel_bench.py (same kernel, same batch; separate counter passes): FETCH_SIZE
+    counts KiB and on gfx950 reports half of a wide coalesced read stream
+    (MI355X_MICROARCH.md, HBM), WRITE_SIZE is exact.  (None, reason) when there is no
+    summary or it was taken from other kernel sources than the present ones (its first line
+    carries their sha256): a counter from another build says nothing about this one.  Never a
+    measurement of the present run, and labelled as such."""
     path = os.path.join(ROOT, PMC_FILE)
+    if not pmc_matches_sources():
+        return None, 'no counter summary of these kernel sources at ' + PMC_FILE
     try:
         fetch = write = None
         take = False
@@ -107,7 +133,10 @@ def pmc_traffic(kernel):
 
 def pmc_counter(kernel, counter):
     """Mean of `counter` per launch of the first kernel whose name contains `kernel` in the
-    committed PMC summary (PMC_FILE; None if absent).  Not a measurement of the present run."""
+    committed PMC summary (PMC_FILE; None if absent or taken from other kernel sources).  Not a
+    measurement of the present run."""
+    if not pmc_matches_sources():
+        return None
     try:
         take = False
         for line in open(os.path.join(ROOT, PMC_FILE)):
@@ -314,6 +343,54 @@ def measure_cfg5(E, local, iters=8):
             'x_realtime': round(nb * ngps / t / 1e3 / 16.368, 1)}
 
 
+def measure_block_length(E, local, n_cyc, iters=8):
+    """The reference's other block lengths (gpsglob.py:122-124: N_CYC "currently possible are
+    (32,16,8)"; 16 / 8 ms position updates "with powerful computers", README.md:24) at
+    CODE_SAMPLES = 2048: 512 MiB of random IQ resident, 12 channels, replay from a synthetic state
+    table (a timing run; parity: tests/test_gpu_trk.py::test_other_block_lengths_*).  The correlator
+    is the span form with one M tile (gpsmi_trk_span.h, template parameter NC)."""
+    cs = 2048
+    ngps = cs * n_cyc
+    nb = (512 << 20) // (ngps * 8)
+    rng = np.random.default_rng(2)
+    trk = E.TrkEngine(E.Config(n_cyc=n_cyc, device=local), max_ch=N_CH)
+    buf = E.DeviceBuffer(nb * ngps * 8, local)
+    chunk = (rng.standard_normal((16, ngps, 2)) * 0.25).astype(np.float32)
+    for i in range(0, nb, 16):
+        buf.upload(chunk[:min(16, nb - i)], i * ngps * 8)
+    for c in range(N_CH):
+        trk.open(c, 2 + c, -4000.0 + 700.0 * c, (173 * c + 11) % cs)
+    st = np.zeros((nb, N_CH), dtype=E.STATE_DTYPE)
+    for c in range(N_CH):
+        st[:, c] = trk.get_state(c)
+    st['phase'] = rng.uniform(0, 6.28, (nb, N_CH)).astype(np.float32)
+    trk.replay_load(nb, st, np.broadcast_to(st['delay'][0], (nb, N_CH)).copy())
+    trk.set_timing(False)
+    for i in range(100):
+        trk.replay_run_async(buf.ptr, nb)
+    trk.wait()
+    trk.set_timing(True)
+    tot, cor = [], []
+    for i in range(iters + 2):
+        trk.replay_run(buf.ptr, nb)
+        if i >= 2:
+            t, c = trk.last_ms()
+            tot.append(t)
+            cor.append(c)
+    variant = trk.get_option('correlator')
+    trk.close()
+    buf.free()
+    t, c = float(np.median(tot)), float(np.median(cor))
+    gb = nb * ngps * 8 / 1e9
+    return {'config': f'N_CYC = {n_cyc} at 2.048 Msps ({n_cyc}-ms blocks): 12-channel tracking, {nb} blocks x '
+                      f'{ngps} complex64 = 512 MiB resident, replay, after 100 untimed runs',
+            'correlator': 'trk_span_kernel<8, 4, 0, 0, %d> (matrix pipe)' % n_cyc if variant else 'trk_stream_kernel (vector)',
+            'correlator_ms': round(c, 4), 'correlator_gbs': round(gb / c * 1e3, 1),
+            'correlator_frac_of_hbm_peak': round(gb / c * 1e3 / HBM_PEAK_GBS, 4),
+            'tracking_all_ms': round(t, 4), 'msamples_per_s': round(nb * ngps / t / 1e3, 1),
+            'x_realtime': round(nb * ngps / t / 1e3 / 2.048, 1)}
+
+
 def measure_batched(E, local, iq_at, nb_avail, chans, Rs=(1, 8, 32, 64), max_steps=64):
     """the closed loop of R independent receivers on one handle
     (gpsmi_trk_set_streams), state fed back on the device block by block, nothing read back
@@ -485,6 +562,35 @@ def measure_multi(E, sharding, dist, torch, lib, comm, rank, world, local, a, nb
         ta = torch.tensor([float(np.mean(acq_ms))], dtype=torch.float64)
         dist.all_reduce(ta, op=dist.ReduceOp.MAX)
         out['sharded_search_us'] = round(float(ta[0]) * 1e3, 1)
+    # ---- the weak-scaling workload of a live installation: R independent receivers per GPU batched
+    # on one handle (gpsmi_trk_set_streams), closed loop, state on the device; the receivers of a
+    # rank read that rank's own blocks; nothing is exchanged
+    R = 64
+    steps = min(16, nb // R)
+    if steps >= 2:
+        trk3 = E.TrkEngine(E.Config(device=local), max_ch=len(chans_all), streams=R)
+        for r in range(R):
+            for c, (s, f, d) in enumerate(chans_all):
+                trk3.open(c, s, f, d, stream=r)
+        trk3.set_timing(False)
+        for i in range(steps):                      # (the first pass uploads the state rows too)
+            trk3.process(d_iq.at(trk_base + i * R * NGPS * 8), want_out=False)
+        E.sync(local)
+        dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            trk3.process(d_iq.at(trk_base + i * R * NGPS * 8), want_out=False)
+        E.sync(local)
+        dt3 = time.perf_counter() - t0
+        trk3.close()
+        rate, total, slowest = sharding.job_rate(dist, steps * R * NGPS, dt3)
+        out['receiver_sharded'] = {
+            'what': f'{R} independent receivers per GPU ({R * world} in all, {len(chans_all)} channels each), '
+                    'closed loop on the device, no collective: the samples of all ranks over the slowest '
+                    "rank's time",
+            'receivers_per_gpu': R, 'receivers': sharding.shard_receivers(R, world - 1)[-1] + 1,
+            'msamples_per_s': round(rate, 1), 'us_per_step_slowest_rank': round(slowest / steps * 1e6, 2),
+            'x_realtime_per_receiver': round(NGPS / (slowest / steps) / 2.048e6, 1), 'scaling': 'weak'}
     # ---- north_star's split: the channels round-robin over the ranks, every rank all NB blocks
     if states is not None:
         mine = sharding.shard_channels(len(chans_all), rank, world)
@@ -877,6 +983,8 @@ def main():
         if world == 1:
             extra.append(measure_u8(E, local, d_raw, nb, chans, states, cl_out['delay_used'], cl_out))
             extra.append(measure_cfg5(E, local))
+            extra.append(measure_block_length(E, local, 16))
+            extra.append(measure_block_length(E, local, 8))
             extra.append(measure_streamed(E, local, raw[N_ACQ_BLOCKS:N_ACQ_BLOCKS + 96], chans))
     dropin = None
     if rank == 0 and world == 1 and not a.no_extra:
@@ -909,6 +1017,12 @@ def main():
             'ms_per_step': round(ms_step, 4), 'higher_is_better': True,
             'scaling': 'strong' if by_channel else 'weak', 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic',
+            'split': ('one GPU' if world == 1 else
+                      'channels (north_star / the reference: one worker per SV; every rank reads all the IQ)'
+                      if by_channel else
+                      'time (replay only): every rank replays its own blocks of the stream from a recorded '
+                      'trajectory -- linear by construction; north_star\'s channel split and the receiver '
+                      'split of a live installation are in multi_gpu.channel_sharded / .receiver_sharded'),
             'config': {
                 'workload': ('BASELINE configs[2]: 12-channel tracking of '
                              f'{nb} x 32 ms blocks (65536 complex64 each, '
@@ -940,6 +1054,11 @@ def main():
                 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
                 'traffic': traffic, 'traffic_source': traffic_src,
+                'traffic_codephase_correlation': (pmc_traffic('trk_corr_kernel<4, 0>')[0] if nb == 1024 else None),
+                'traffic_note': 'HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE) from the committed counter '
+                                'pass, null unless that pass was taken from the present kernel sources; the '
+                                'code-phase correlation reads the 134 MB of centre rows (one fetch per block: '
+                                'its channel groups share an XCD)',
                 'kernel_ms': round(k_ms, 4),
                 'kernel_ms_source': 'hipExtLaunchKernel begin/end events, mean over the timed steps of the '
                                     'isolated pass (the kernel alone on the chip, steady clocks)',

@@ -459,14 +459,14 @@ __global__ __launch_bounds__(kPfaThreads) void pfa_corr_kernel(
 
 // all correlations of `ncell` cells on `stream`, statistics included
 inline void pfa_corr_launch(hipStream_t stream, const float2* x, const int* xsel, const int* rsel,
-                            int ncell, float2* RS, DirStats* stats) {
+                            int ncell, float2* RS, DirStats* stats, int cell0 = 0) {
     if (ncell <= 0) return;
     int dev = 0, n_cu = 256;
     if (hipGetDevice(&dev) == hipSuccess)
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
     const int grid = ncell < n_cu ? ncell : n_cu;
     hipLaunchKernelGGL(pfa_corr_kernel<0>, dim3(grid), dim3(kPfaThreads), 0, stream, x,
-                       (const float*)nullptr, xsel, rsel, RS, 0, ncell, stats);
+                       (const float*)nullptr, xsel, rsel, RS, cell0, ncell, stats);
 }
 
 // spectrum of the replica in slot `slot` (rep_slot0 = table of real replicas [slots][L])

@@ -538,6 +538,7 @@ struct gpsmi_trk {
                                      // the default where it applies; 0: another correlator
     int codephase = 0;               // option "codephase" as taken at create time
     int corr_overlap = 0;            // option "corr_overlap": see gpsmi_trk_replay_run_async
+    int fold_chunk = 0;              // option "fold_chunk": blocks per fold -> correlation piece at CS = 16368
     float* d_code_eo = nullptr;      // [GPSMI_MAX_PRN + 1][...]: the replica re-cut for the matrix correlators.  Span form
                                      // (2048): four planes by index mod 4, entry h of plane e = replica[(4 h + e) mod 2048],
                                      // 1024 entries each (a lane's run never wraps); span8 form: two planes by index
@@ -648,12 +649,22 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
     // ---- code-phase correlation
     if (h->general) {
         const int cs = P.cs;
-        hipLaunchKernelGGL(trk_fold_general_kernel, dim3((cs + 255) / 256, nblocks), dim3(256), 0,
-                           rs, d_iq, h->d_t32, st_in, P, h->d_fold, h->d_xsel, h->d_rsel,
-                           sl.d_mid);
-        if (h->pfa)              // transform, product, transform and statistics in one launch
-            pfa_corr_launch(rs, h->d_fold, h->d_xsel, h->d_rsel, njobs, h->d_RSp, h->d_stats);
-        else if (h->big)
+        // The folded samples (nch x cs complex64 per block: 805 MB for a 512-block batch at 16368) are an
+        // intermediate between two kernels: with the native-length correlation they go through in
+        // pieces of `fold_chunk` blocks that reuse one scratch area, so that what the fold writes is
+        // still in the memory-side cache when the correlation reads it (option "fold_chunk"; 0: the
+        // whole launch at once)
+        const int chunk = (h->pfa && h->fold_chunk > 0 && h->fold_chunk < nblocks) ? h->fold_chunk : nblocks;
+        for (int b0 = 0; b0 < nblocks; b0 += chunk) {
+            const int nbc = nblocks - b0 < chunk ? nblocks - b0 : chunk;
+            hipLaunchKernelGGL(trk_fold_general_kernel, dim3((cs + 255) / 256, nbc), dim3(256), 0,
+                               rs, d_iq, h->d_t32, st_in, P, h->d_fold, h->d_xsel, h->d_rsel,
+                               sl.d_mid, b0);
+            if (h->pfa)              // transform, product, transform and statistics in one launch
+                pfa_corr_launch(rs, h->d_fold, h->d_xsel, h->d_rsel, nbc * nch, h->d_RSp, h->d_stats, b0 * nch);
+        }
+        if (h->pfa) {
+        } else if (h->big)
             big_corr_launch(rs, h->d_fold, h->d_xsel, h->d_rsel, njobs, cs, h->d_RS, h->d_S,
                             h->d_tw, h->d_twN, h->d_mag);
         else
@@ -1067,7 +1078,7 @@ static int trk_build(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk* h) {
     const struct { const char* key; long long fallback; } tun[] = {
         {"corr_cg", h->corr_cg}, {"span_single_max", h->span_single_max}, {"stream_inline_max", (long long)h->stream_inline_max},
         {"done_by_dispatch", h->done_by_dispatch}, {"corr_overlap", h->corr_overlap},
-        {"stream_thread", h->stream_thread}, {"stream_depth", h->stream_depth}};
+        {"stream_thread", h->stream_thread}, {"stream_depth", h->stream_depth}, {"fold_chunk", h->fold_chunk}};
     for (const auto& t : tun) {
         default_opt(t.key, &v, t.fallback);
         if (v != t.fallback) (void)gpsmi_trk_set_option(h, t.key, v);   // (an out-of-range default is ignored)
@@ -1691,6 +1702,9 @@ int gpsmi_trk_set_option(gpsmi_trk* h, const char* key, long long value) {
         h->done_by_dispatch = value != 0;
     } else if (!strcmp(key, "corr_overlap")) {
         h->corr_overlap = value != 0;
+    } else if (!strcmp(key, "fold_chunk")) {
+        if (value < 0 || value > (1 << 20)) return bad();
+        h->fold_chunk = (int)value;
     } else if (!strcmp(key, "stream_thread")) {
         h->stream_thread = value != 0;
     } else if (!strcmp(key, "stream_depth")) {
@@ -1714,6 +1728,7 @@ int gpsmi_trk_get_option(gpsmi_trk* h, const char* key, long long* value) {
     else if (!strcmp(key, "stream_inline_max")) *value = (long long)h->stream_inline_max;
     else if (!strcmp(key, "done_by_dispatch")) *value = h->done_by_dispatch;
     else if (!strcmp(key, "corr_overlap")) *value = h->corr_overlap;
+    else if (!strcmp(key, "fold_chunk")) *value = h->fold_chunk;
     else if (!strcmp(key, "stream_thread")) *value = h->stream_thread;
     else if (!strcmp(key, "stream_depth")) *value = h->stream_depth;
     else if (!strcmp(key, "stat_stream_steps")) *value = h->stat_steps;

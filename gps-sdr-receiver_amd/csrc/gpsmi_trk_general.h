@@ -30,12 +30,14 @@ constexpr int kGenFoldRows = 8;      // rows held in registers (CORR_AVG of the 
 __global__ __launch_bounds__(256) void trk_fold_general_kernel(
     const float2* __restrict__ iq, const float* __restrict__ t32,
     const gpsmi_trk_state* __restrict__ st_in, TrkParams P, float2* __restrict__ fold,
-    int* __restrict__ xsel, int* __restrict__ rsel, JobMid* __restrict__ mid) {
+    int* __restrict__ xsel, int* __restrict__ rsel, JobMid* __restrict__ mid, int b0) {
+    // (b0: first block of this launch; the folded samples are written chunk-local, fold[(b - b0) ...],
+    // so that a batch can go through the fold and the correlation in pieces that stay in the cache)
     (void)t32;
     __shared__ float2 urow[kGenFoldCh][32];              // corr_avg <= n_cyc <= 32
     __shared__ float s_om[kGenFoldCh], s_ph[kGenFoldCh];
     __shared__ int s_active[kGenFoldCh];
-    const int b = blockIdx.y, t = threadIdx.x, m = blockIdx.x * 256 + t;
+    const int b = b0 + blockIdx.y, t = threadIdx.x, m = blockIdx.x * 256 + t;
     const int cs = P.cs, nch = P.nch;
     const int first = (P.n_cyc - P.corr_avg) / 2;
     const double inv_2pi = 0.15915494309189533576888376337251;
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(256) void trk_fold_general_kernel(
                     md.om = om; md.ph = ph;
                     md.pad[0] = md.pad[1] = md.pad[2] = 0;
                     mid[job] = md;
-                    xsel[job] = job;
+                    xsel[job] = job - b0 * nch;
                     rsel[job] = md.prn;
                 }
             }
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256) void trk_fold_general_kernel(
                     const float2 v = phasor_rev(fmaf(f_eff, tm, s_ph[c] * (float)inv_2pi));
                     r = cmulf(make_float2(acc.x * sc, acc.y * sc), v);
                 }
-                fold[(size_t)(b * nch + c0 + c) * cs + m] = r;
+                fold[(size_t)((b - b0) * nch + c0 + c) * cs + m] = r;
             }
         }
         __syncthreads();                                   // (the tables are rewritten for the next pass)

@@ -17,7 +17,12 @@ Tracking, two splits:
    cut up: strong scaling.
  * in TIME (shard_blocks): rank r tracks its own segment of the stream from a
    known trajectory (replay).  Per-rank work is fixed: weak scaling; this is what
-   bench.py --gpus N times by default, the other with --shard channels."""
+   bench.py --gpus N times by default, the other with --shard channels.  The split exists
+   for REPLAY only (a live stream has no recorded trajectory to start a later segment from).
+ * by RECEIVER (shard_receivers): the weak-scaling workload of a live installation --
+   independent receivers (antennas / IQ streams), R per GPU batched on one tracking handle
+   (gpsmi_trk_set_streams), closed loop.  Receivers share nothing: no collective; the job's rate
+   is the samples of all ranks over the slowest rank's time (job_rate)."""
 import numpy as np
 
 
@@ -75,6 +80,31 @@ def merge_peak_tables(gathered, prns, world):
         n = len(shard_svs(prns, r, world))
         cols.append(gathered[r][:, :n])
     return np.concatenate(cols, axis=1)
+
+
+def shard_receivers(per_gpu, rank):
+    """Global ids of the independent receivers rank `rank` tracks: per_gpu on every GPU."""
+    return list(range(rank * per_gpu, (rank + 1) * per_gpu))
+
+
+def merge_receiver_tables(parts):
+    """parts[r]: array [per_gpu, ...] of rank r's per-receiver results -> [world * per_gpu, ...]
+    in global receiver order (the inverse of shard_receivers)."""
+    return np.concatenate(parts, axis=0)
+
+
+def job_rate(dist, samples, seconds):
+    """Whole-job throughput of a sharded run with no data-path collective: the samples of all
+    ranks over the SLOWEST rank's time (bench.py's max-over-ranks).  dist: torch.distributed or
+    None (one process).  -> (Msamples/s, total samples, slowest seconds)."""
+    if dist is None:
+        return samples / seconds / 1e6, int(samples), float(seconds)
+    import torch
+    t = torch.tensor([float(samples), 0.0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    m = torch.tensor([float(seconds)], dtype=torch.float64)
+    dist.all_reduce(m, op=dist.ReduceOp.MAX)
+    return float(t[0]) / float(m[0]) / 1e6, int(t[0]), float(m[0])
 
 
 class CountMismatch(ValueError):

@@ -132,6 +132,58 @@ def test_channel_sharded_tracking_merge_world2():
     assert ok and shape == (3, 3)
 
 
+def _receiver_worker(rank, world, port, q):
+    """Receiver-sharded tracking, the weak-scaling workload of a live installation: every rank
+    tracks ITS independent receivers (each its own IQ stream), nothing is exchanged on the data
+    path; the per-receiver results gathered in global receiver order must equal the one-process
+    run of all receivers, and the job's rate is all samples over the slowest rank's time.
+    Stand-in compute: the oracle's SatStream (on the GPU: gpsmi_trk_set_streams)."""
+    sys.path[:0] = [os.path.join(ROOT, 'gps-sdr-receiver_amd'), os.path.join(ROOT, 'oracle')]
+    import torch
+    import torch.distributed as dist
+    import gps_oracle as orc
+    from gpsmi import sharding, synth
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    p = orc.Params()
+    per_gpu, nb = 2, 2
+    rec_dt = np.dtype([('receiver', 'i4'), ('delay', 'i4'), ('freq', 'f4'), ('code_phase', 'f8')])
+
+    def run(ids):
+        out = np.zeros(len(ids), dtype=rec_dt)
+        for k, g in enumerate(ids):                      # receiver g: its own scene (seed)
+            sc = synth.default_scene(2, seed=100 + g)
+            s = sc.sats[0]
+            ss = orc.SatStream(s.prn, round(s.doppler / 200.0) * 200.0, p, delay=int(round(s.delay)) % 2048)
+            for i in range(nb):
+                _, _, co_ph, _ = ss.process(sc.block(i), np.int64((i + 1) * p.ngps))
+            out[k] = (g, ss.delay, ss.freq, co_ph)
+        return out
+
+    mine = sharding.shard_receivers(per_gpu, rank)
+    loc = run(mine)
+    send = torch.from_numpy(loc.view(np.uint8).copy())
+    recv = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(recv, send)           # (result check only: the data path has no collective)
+    merged = sharding.merge_receiver_tables([r.numpy().view(rec_dt) for r in recv])
+    rate, total, slowest = sharding.job_rate(dist, per_gpu * nb * p.ngps, 0.5 * (rank + 1))
+    dist.barrier()
+    if rank == 0:
+        full = run(list(range(world * per_gpu)))
+        q.put((merged.tobytes() == full.tobytes(), list(merged['receiver']), rate, total, slowest))
+    dist.destroy_process_group()
+
+
+def test_receiver_sharded_tracking_merge_world2():
+    ok, ids, rate, total, slowest = _run_world(_receiver_worker, 2)
+    assert ok and ids == [0, 1, 2, 3]
+    assert total == 2 * 2 * 2 * 65536 and slowest == 1.0          # all samples, the slowest rank's time
+    assert abs(rate - total / 1.0 / 1e6) < 1e-9
+    from gpsmi import sharding
+    assert sharding.job_rate(None, 1000, 0.5) == (0.002, 1000, 0.5)
+    assert sharding.shard_receivers(64, 3) == list(range(192, 256))
+
+
 def test_shards_tile_the_sv_list():
     from gpsmi import sharding
     prns = list(range(1, 33))

@@ -7,6 +7,11 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
+if '--stamp' in sys.argv:          # first line: the kernel sources the counters were taken from
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    print('# csrc_sha256', bench.csrc_sha256())
 acc = defaultdict(lambda: defaultdict(list))
 for f in sorted(glob.glob(root + '/**/*counter_collection.csv', recursive=True)):
     for row in csv.DictReader(open(f)):

@@ -34,7 +34,7 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY 
   timeout -k 10 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/pmc/acq2_pass$i -- python3 tools/acq_bench.py --iters 3 --grid cfg2 > $out/pmc_acq2$i.log 2>&1 || { echo "pmc acq2 pass $i failed"; tail -5 $out/pmc_acq2$i.log; }
   echo "pmc pass $i done"
 done
-python3 tools/pmc_summary.py $out/pmc > $out/pmc_counters.txt
+python3 tools/pmc_summary.py $out/pmc --stamp > $out/pmc_counters.txt
 rm -rf $out/pmc
 fi
 if [ $part = rest ] || [ $part = all ]; then
