@@ -1,6 +1,6 @@
 import sys, os, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, 'gps-sdr-receiver_amd')]
 from gpsmi import synth, engine as E
 from gpsmi.pipeline import Receiver

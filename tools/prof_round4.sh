@@ -44,6 +44,14 @@ tools/probe/chain_floor > $out/chain_floor.txt 2>&1 || echo "chain_floor failed"
 python3 tools/kernel_bench.py > $out/kernel_bench.txt 2>&1
 python3 tools/kernel_bench.py --delays aligned >> $out/kernel_bench.txt 2>&1
 python3 tools/kernel_bench.py --code-samples 16368 --n-cyc 8 --blocks 512 --iters 5 >> $out/kernel_bench.txt 2>&1
+python3 tools/kernel_bench.py --n-cyc 16 --blocks 2048 >> $out/kernel_bench.txt 2>&1
+python3 tools/kernel_bench.py --n-cyc 8 --blocks 4096 >> $out/kernel_bench.txt 2>&1
+GPSMI_STREAM_MFMA=0 python3 tools/kernel_bench.py --n-cyc 16 --blocks 2048 >> $out/kernel_bench.txt 2>&1
+GPSMI_STREAM_MFMA=0 python3 tools/kernel_bench.py --n-cyc 8 --blocks 4096 >> $out/kernel_bench.txt 2>&1
+for ch in 0 64 128; do echo "fold_chunk $ch" >> $out/kernel_bench.txt; GPSMI_FOLD_CHUNK=$ch python3 tools/kernel_bench.py --code-samples 16368 --n-cyc 8 --blocks 512 --iters 8 2>&1 | tail -1 >> $out/kernel_bench.txt; done
+python3 tools/prof_feed.py > $out/dropin_profile.txt 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $out/feed -- python3 tools/feed_trace.py > $out/feed_trace.log 2>&1 \
+  && python3 tools/trace_summary.py $out/feed > $out/feed_trace_summary.txt; rm -rf $out/feed
 python3 tools/acq_bench.py --hirate > $out/acq_bench.txt 2>&1
 python3 tools/batched_bench.py > $out/batched_bench.txt 2>&1
 python3 tools/stream_bench.py > $out/stream_bench.txt 2>&1
