@@ -815,19 +815,21 @@ def main():
     cold_corr_ms, cp_ms = [], []
     ovl = {'total': [], 'corr': [], 'cp': []}      # the same kernels' times inside the overlapped pipeline
 
-    def record_last(cold=False):
+    def record_last(cold=False, full=True):
         t, c = trk.last_ms()
         if cold == 'cold':
             cold_corr_ms.append(c)
             return
         if cold == 'overlapped':
-            ovl['total'].append(t)
             ovl['corr'].append(c)
-            ovl['cp'].append(trk.last_codephase_ms())
+            if full:
+                ovl['total'].append(t)
+                ovl['cp'].append(trk.last_codephase_ms())
             return
-        total_ms.append(t)
         corr_ms.append(c)
-        cp_ms.append(trk.last_codephase_ms())
+        if full:
+            total_ms.append(t)
+            cp_ms.append(trk.last_codephase_ms())
 
     def gather_peaks():
         """all-gather of the (padded, equal-sized) shard tables -> `gathered`"""
@@ -861,7 +863,9 @@ def main():
         acq.engine.after(trk)
         # the kernel-timing events of the other kernels are barrier packets in the queue
         # (~5 us each): the kernels of every fourth step are timed, the others run without
-        trk.set_timing(k % TIMED_EVERY == 0)
+        # (on the steps between, only the correlator's own dispatch stamps are taken: no packet in
+        # the queue, so the roofline kernel's duration is the mean over EVERY timed step)
+        trk.set_timing(1 if k % TIMED_EVERY == 0 else 2)
         # (the tracking batch goes into its queue first: its first kernel is what the GPU is
         # waiting for when the host is late; the search has the whole of that kernel's time)
         trk.replay_run_async(d_iq.at(trk_base), nb)
@@ -869,8 +873,8 @@ def main():
                                 d_send.ptr if world > 1 else None)
         trk.replay_fetch_async(pins[k & 1].array)
         trk.wait_prev()
-        if record and k > 0 and (k - 1) % TIMED_EVERY == 0:
-            record_last(cold=record)
+        if record and k > 0:
+            record_last(cold=record, full=(k - 1) % TIMED_EVERY == 0)
 
     # Settling: an idle MI355X needs some 40 ms under load before its clocks stop moving - the
     # same correlator launch takes ~120 us at the start of a run and ~103 us from the 100th
@@ -911,8 +915,7 @@ def main():
     trk.wait()                              # ... its kernels and its copy
     barrier()
     dt = time.perf_counter() - t0
-    if (a.steps - 1) % TIMED_EVERY == 0:
-        record_last('overlapped' if overlap else False)
+    record_last('overlapped' if overlap else False, full=(a.steps - 1) % TIMED_EVERY == 0)
     recording[0] = False
     # the other pipeline, OVL_STEPS steps (untimed for `value`)
     trk.set_option('corr_overlap', 0 if overlap else 1)
@@ -1039,6 +1042,7 @@ def main():
                           '"corr_overlap"), the code-phase correlation of batch k + 1 runs beside the '
                           'correlator of batch k') if overlap else
                          'isolated: one batch at a time, every kernel alone on the chip',
+                'other_pass_steps': OVL_STEPS + 4,
                 'isolated_ms_per_step': round(other_ms_step if overlap else ms_step, 4),
                 'overlapped_ms_per_step': round(ms_step if overlap else other_ms_step, 4),
                 'note': f'the pipeline that is not the timed one ran {OVL_STEPS} steps behind the timed region; '
@@ -1060,8 +1064,9 @@ def main():
                                 'code-phase correlation reads the 134 MB of centre rows (one fetch per block: '
                                 'its channel groups share an XCD)',
                 'kernel_ms': round(k_ms, 4),
-                'kernel_ms_source': 'hipExtLaunchKernel begin/end events, mean over the timed steps of the '
-                                    'isolated pass (the kernel alone on the chip, steady clocks)',
+                'kernel_ms_source': 'hipExtLaunchKernel begin/end stamps of the dispatch, mean over ALL '
+                                    f'{len(corr_ms)} steps of the isolated pass (the kernel alone on the chip, '
+                                    'steady clocks)',
                 'algorithmic_bytes_per_launch': alg_bytes,
                 'frac_vs_measured_copy': round(achieved / HBM_COPY_GBS, 4),
                 'frac_cold': round(alg_bytes / (float(np.mean(cold_corr_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)

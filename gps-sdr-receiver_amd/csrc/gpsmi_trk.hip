@@ -500,7 +500,8 @@ struct gpsmi_trk {
         hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // start, corr done, correlator done, end
         hipEvent_t ready = nullptr, copied = nullptr;
         hipEvent_t corr_done = nullptr, epi_done = nullptr;   // correlator / epilogue of the slot's run
-        bool copy_pending = false, timing_pending = false, epi_pending = false;
+        bool copy_pending = false, epi_pending = false;
+        int timing_pending = 0;              // the timing mode of the slot's run, until its times are taken
         JobMid* d_mid = nullptr;             // per-job descriptors and window sums of the slot's run
         float2* d_partial = nullptr;
         hipStream_t run_stream = nullptr;    // "corr_overlap": the stream the slot's runs are enqueued on (null: h->stream)
@@ -509,7 +510,9 @@ struct gpsmi_trk {
                                              // while run k + 1 writes the other slot's
     } slot[2];
     int cur = 0;                         // slot of the latest launch
-    bool timing = true;                  // record the four kernel-timing events per launch
+    int timing = 1;                      // 1: record the four kernel-timing events per launch; 2: only the
+                                         // begin / end stamps of the batch correlator's own dispatch (no
+                                         // packet in the queue); 0: none
     float2* d_tw = nullptr;
     float* d_t32 = nullptr;
     float2* d_rep = nullptr;         // [GPSMI_MAX_PRN + 1][cs] spectra
@@ -637,7 +640,8 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
     h->main_tail = nullptr;
     const float2* d_iq = static_cast<const float2*>(d_iq_v);       // (raw uint16 when iq_fmt says so)
     const bool u8 = h->iq_fmt == GPSMI_IQ_U8;
-    const bool timed = h->timing;        // each event record is a barrier packet (~5 us of bubble)
+    const bool timed = h->timing == 1;   // each event record is a barrier packet (~5 us of bubble)
+    const bool corr_stamps = h->timing == 2;
     if (timed) GPSMI_HIP(hipEventRecord(sl.ev[0], rs));
     const int nblocks = njobs / nch;
     const int ngroups = (nch + kGroupCh - 1) / kGroupCh;
@@ -706,7 +710,7 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
     // correlator are the dispatch's own begin / end stamps (hipExtLaunchKernel: what a kernel
     // trace reports), not event records around it: no barrier packets next to the kernel and
     // no launch gap inside the pair.
-    const bool ext_timed = timed && h->mfma == 4 && !span_single;
+    const bool ext_timed = (timed || corr_stamps) && h->mfma == 4 && !span_single;
     bool corr_done_recorded = false;
     // batch form of the span correlator: persistent workgroups, two per CU, an equal number of
     // (block, channel group) units each
@@ -820,10 +824,12 @@ HandleSync trk_sync(gpsmi_trk* h);
 // kernel times of a finished launch into last_*_ms
 static int trk_take_timing(gpsmi_trk* h, gpsmi_trk::Slot& sl) {
     if (!sl.timing_pending) return GPSMI_OK;
-    GPSMI_HIP(hipEventElapsedTime(&h->last_total_ms, sl.ev[0], sl.ev[3]));
+    if (sl.timing_pending == 1) {
+        GPSMI_HIP(hipEventElapsedTime(&h->last_total_ms, sl.ev[0], sl.ev[3]));
+        GPSMI_HIP(hipEventElapsedTime(&h->last_cp_ms, sl.ev[0], sl.ev[1]));
+    }
     GPSMI_HIP(hipEventElapsedTime(&h->last_corr_ms, sl.ev[1], sl.ev[2]));
-    GPSMI_HIP(hipEventElapsedTime(&h->last_cp_ms, sl.ev[0], sl.ev[1]));
-    sl.timing_pending = false;
+    sl.timing_pending = 0;
     return GPSMI_OK;
 }
 
@@ -1280,9 +1286,9 @@ int gpsmi_trk_process_dev(gpsmi_trk* h, const void* d_iq, size_t n, gpsmi_trk_ou
                                  hipMemcpyDeviceToHost, h->stream));
     // nothing to hand back: the block is enqueued, the state stays on the device and the
     // next call queues behind it (get_state / wait / a call with `out` synchronise)
-    if (!out && !h->timing) return GPSMI_OK;
+    if (!out && h->timing != 1) return GPSMI_OK;
     GPSMI_HIP(hipStreamSynchronize(h->stream));
-    if (h->timing) {
+    if (h->timing == 1) {
         GPSMI_HIP(hipEventElapsedTime(&h->last_total_ms, sl.ev[0], sl.ev[3]));
         GPSMI_HIP(hipEventElapsedTime(&h->last_corr_ms, sl.ev[1], sl.ev[2]));
         GPSMI_HIP(hipEventElapsedTime(&h->last_cp_ms, sl.ev[0], sl.ev[1]));
@@ -1382,8 +1388,8 @@ static int trk_stream_step(gpsmi_trk* h, const void* iq, size_t n, gpsmi_trk_out
     gpsmi_trk::Slot& sl = h->slot[0];
     h->cur = 0;
     sl.run_stream = nullptr;
-    const bool timing = h->timing;
-    h->timing = false;                      // (no kernel-timing events in a streaming loop)
+    const int timing = h->timing;
+    h->timing = 0;                          // (no kernel-timing events in a streaming loop)
     gpsmi_trk_out* const d_out_keep = sl.d_out;
     if (out_direct) sl.d_out = static_cast<gpsmi_trk_out*>(out_dev);
     rc = trk_launch(h, sl, h->d_stage[s], h->d_state, h->d_state, nullptr, h->rows(), h->max_ch);
@@ -1512,7 +1518,9 @@ int gpsmi_trk_replay_run_async(gpsmi_trk* h, const void* d_iq, int nb) {
         GPSMI_HIP(hipStreamWaitEvent(rs, sl.epi_done, 0));
         sl.epi_pending = false;
     }
-    sl.timing_pending = h->timing;
+    // (mode 2 needs the batch form of the span correlator: its dispatch carries the stamps)
+    sl.timing_pending = (h->timing == 2 && !(h->mfma == 4 && nb * ((nch + kSpCh - 1) / kSpCh) > h->span_single_max))
+                            ? 0 : h->timing;
     return trk_launch(h, sl, d_iq, h->d_tab_in, h->d_tab_out,
                       h->replay_forced ? h->d_forced : nullptr, nb * nch, nch, /*side_epilogue=*/true);
 }
@@ -1547,7 +1555,7 @@ int gpsmi_trk_wait_prev(gpsmi_trk* h) {
         sl.copy_pending = false;
         sl.epi_pending = false;            // (the copy was queued behind the slot's epilogue)
     } else if (sl.timing_pending) {
-        GPSMI_HIP(hipEventSynchronize(sl.ev[3]));
+        GPSMI_HIP(hipEventSynchronize(sl.ev[sl.timing_pending == 1 ? 3 : 2]));
     }
     return trk_take_timing(h, sl);
 }
@@ -1758,7 +1766,7 @@ int gpsmi_trk_corr_wg_map(int nblocks, int ngroups, int wg, int* block, int* gro
 int gpsmi_trk_set_timing(gpsmi_trk* h, int on) {
     GPSMI_REQUIRE(h, "null handle");
     GPSMI_QUIESCE(h);
-    h->timing = on != 0;
+    h->timing = on == 2 ? 2 : (on != 0);
     return GPSMI_OK;
 }
 

@@ -411,7 +411,7 @@ class TrkEngine:
 
     def set_timing(self, on):
         """Kernel-timing events for the launches that follow (see gpsmi.h)."""
-        check(self.lib.gpsmi_trk_set_timing(self.h, int(bool(on))), 'gpsmi_trk_set_timing')
+        check(self.lib.gpsmi_trk_set_timing(self.h, 2 if on == 2 else int(bool(on))), 'gpsmi_trk_set_timing')
 
     def wait_prev(self):
         """The run before the latest one, and its read-back, are done."""

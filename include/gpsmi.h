@@ -349,9 +349,11 @@ int gpsmi_acq_after_trk(gpsmi_acq* later, gpsmi_trk* earlier);
 int gpsmi_trk_replay_states(gpsmi_trk* h, gpsmi_trk_state* states, size_t n);
 /* Device time of the last process/replay call (HIP events on the handle's
  * stream), total and for the correlator kernel alone, ms.                     */
-/* Kernel-timing events around the launches that follow (default on).  Each of the four
+/* Kernel-timing events around the launches that follow (default on = 1).  Each of the four
  * event records is a barrier packet in the queue, ~5 us of pipeline bubble: a caller
- * that does not read gpsmi_trk_last_ms switches them off, a benchmark samples.   */
+ * that does not read gpsmi_trk_last_ms switches them off (0), a benchmark samples.  on = 2:
+ * only the begin / end stamps of the batch correlator's own dispatch are taken (no packet in
+ * the queue: free), gpsmi_trk_last_ms then updates correlator_ms alone.                  */
 int gpsmi_trk_set_timing(gpsmi_trk* h, int on);
 /* Options of one handle (keys: the table at gpsmi_set_default).  get reports what is in effect --
  * for "correlator" / "codephase" the variant the handle actually runs.                  */

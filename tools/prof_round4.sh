@@ -14,7 +14,8 @@ echo "bench done"
 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py > $out/bench_prof_line.json 2> $out/bench_prof.err || { echo prof failed; tail -5 $out/bench_prof.err; exit 1; }
 echo "bench under rocprofv3 done"
 python3 tools/prof_summary.py $(find $out/stats -name "*kernel_trace.csv" | head -1) > $out/bench_kernel_table.md
-python3 tools/step_timeline.py $out/stats 2 > $out/step_timeline.txt
+python3 tools/step_timeline.py $out/stats 2 28 > $out/step_timeline.txt
+python3 tools/step_timeline.py $out/stats 2 0 > $out/step_timeline_overlapped.txt
 python3 tools/timed_region.py $out/stats $out/bench_prof_line.json > $out/bench_kernel_summary.md
 find $out/stats -name "*kernel_stats.csv" -exec cp {} $out/bench_kernel_stats.csv \;
 rm -rf $out/stats
