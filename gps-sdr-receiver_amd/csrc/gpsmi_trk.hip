@@ -499,6 +499,7 @@ struct gpsmi_trk {
         gpsmi_trk_out* d_out = nullptr;
         hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // start, corr done, correlator done, end
         hipEvent_t ready = nullptr, copied = nullptr;
+        hipEvent_t corr_stop = nullptr;      // the event that carries the end stamp of the slot's timed correlator
         hipEvent_t corr_done = nullptr, epi_done = nullptr;   // correlator / epilogue of the slot's run
         bool copy_pending = false, epi_pending = false;
         int timing_pending = 0;              // the timing mode of the slot's run, until its times are taken
@@ -640,6 +641,7 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
     h->main_tail = nullptr;
     const float2* d_iq = static_cast<const float2*>(d_iq_v);       // (raw uint16 when iq_fmt says so)
     const bool u8 = h->iq_fmt == GPSMI_IQ_U8;
+    sl.corr_stop = sl.ev[2];
     const bool timed = h->timing == 1;   // each event record is a barrier packet (~5 us of bubble)
     const bool corr_stamps = h->timing == 2;
     if (timed) GPSMI_HIP(hipEventRecord(sl.ev[0], rs));
@@ -728,7 +730,8 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
     do {                                                                                                      \
         if (ext_timed && (NSP) == 8)                                                                          \
             hipExtLaunchKernelGGL((trk_span_kernel<NSP, WV, FMTV, 0, NCV>), GRID, BLOCK, 0, rs, sl.ev[1],     \
-                                  sl.ev[2], 0, d_iq_v, cmid, ceo, P, ng12, nblocks, sl.d_rec, sl.d_partial);  \
+                                  sl.corr_stop, 0, d_iq_v, cmid, ceo, P, ng12, nblocks, sl.d_rec,             \
+                                  sl.d_partial);                                                              \
         else if (by_dispatch && (NSP) == 8)                                                                   \
             hipExtLaunchKernelGGL((trk_span_kernel<NSP, WV, FMTV, 0, NCV>), GRID, BLOCK, 0, rs, nullptr,      \
                                   sl.corr_done, 0, d_iq_v, cmid, ceo, P, ng12, nblocks, sl.d_rec,             \
@@ -747,7 +750,10 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
         // replay: the event the epilogue stream (and a search) waits for is the completion signal of
         // this very dispatch, not a record behind it - a record is one more barrier packet between
         // this kernel and the next batch's first one
-        const bool by_dispatch = !ext_timed && !span_single && side_epilogue && h->done_by_dispatch;
+        const bool by_dispatch = !span_single && side_epilogue && h->done_by_dispatch;
+        // (a timed launch that is also the one the epilogue stream waits for: ONE stop event serves
+        // both -- the dispatch's completion signal -- instead of a record packet behind the kernel)
+        sl.corr_stop = (ext_timed && by_dispatch) ? sl.corr_done : sl.ev[2];
         if (P.n_cyc == 32) GPSMI_LAUNCH_SPAN_NC(32);
         else if (P.n_cyc == 16) GPSMI_LAUNCH_SPAN_NC(16);
         else GPSMI_LAUNCH_SPAN_NC(8);
@@ -828,7 +834,7 @@ static int trk_take_timing(gpsmi_trk* h, gpsmi_trk::Slot& sl) {
         GPSMI_HIP(hipEventElapsedTime(&h->last_total_ms, sl.ev[0], sl.ev[3]));
         GPSMI_HIP(hipEventElapsedTime(&h->last_cp_ms, sl.ev[0], sl.ev[1]));
     }
-    GPSMI_HIP(hipEventElapsedTime(&h->last_corr_ms, sl.ev[1], sl.ev[2]));
+    GPSMI_HIP(hipEventElapsedTime(&h->last_corr_ms, sl.ev[1], sl.corr_stop ? sl.corr_stop : sl.ev[2]));
     sl.timing_pending = 0;
     return GPSMI_OK;
 }
@@ -1555,7 +1561,7 @@ int gpsmi_trk_wait_prev(gpsmi_trk* h) {
         sl.copy_pending = false;
         sl.epi_pending = false;            // (the copy was queued behind the slot's epilogue)
     } else if (sl.timing_pending) {
-        GPSMI_HIP(hipEventSynchronize(sl.ev[sl.timing_pending == 1 ? 3 : 2]));
+        GPSMI_HIP(hipEventSynchronize(sl.timing_pending == 1 ? sl.ev[3] : (sl.corr_stop ? sl.corr_stop : sl.ev[2])));
     }
     return trk_take_timing(h, sl);
 }

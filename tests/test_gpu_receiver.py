@@ -245,3 +245,60 @@ def test_a_subset_call_leaves_the_other_channels_alone(golden_default):
         assert [(x[0], x[1], x[3], tuple(map(float, x[4]))) for x in ra] == \
                [(x[0], x[1], x[3], tuple(map(float, x[4]))) for x in rb]
     assert st_a == st_b
+
+
+@pytest.mark.parametrize('lazy', [False, True])
+def test_bad_correlation_history_triggers_the_sweep(lazy):
+    """checkCorrQuality (gpslib.py:1134-1138): at a report block, with a minute of correlation
+    history whose mean is below -0.9, process() calls initSweep INSTEAD of the PLL -- FREQ_SAVE /
+    DF_SAVE are the values before that block's update, PHASE_LOCKED / CORRLST / MS_TIME are reset,
+    and the next blocks run sweepFrequency.  The history is planted (a minute of failed
+    correlations is 1,920 blocks), the channel tracks a satellite that is not in the scene, and the
+    same is done to the oracle's SatStream; per-block calls and the lazy path (whose steady state
+    must notice that a trigger is possible and take the per-block route for that block)."""
+    from collections import deque
+    import gps_oracle as orc
+    from gpsmi import receiver as R
+    p = orc.Params()
+    sv, f0, d0 = 3, 1234.5, 100                       # PRN 3 is not in the default scene
+    first, nb = 58, 12                                # streams 59 .. 70: report block at 64
+    blocks = scene_blocks('default', first, nb)
+    pool, n, worker = R.initMultiProcPool(1)
+    worker, act = R.initPoolStreams(pool, n, worker, set(), {sv}, [(20.0, sv, f0, d0)])
+    ss = orc.SatStream(sv, f0, p, delay=d0)
+    hc = pool.chan[0]
+    planted = [-1] * (hc.CORRLST_NO - 3)
+    hc.CORRLST = deque([0] + planted, maxlen=hc.CORRLST_NO)
+    hc._corr_sum = -len(planted)
+    ss.corrlst = [0] + planted
+    got = []
+    for i in range(nb):
+        smp = np.int64((first + i + 1) * 65536)
+        sw_ref, fl_ref, cp_ref, (cq_ref, cl_ref) = ss.process(blocks[i], smp)
+        if lazy:
+            batches = R.satCalcLazy(act, pool, worker, blocks[i], smp)
+            if (first + i + 1) % 32 != 0 and not hc.SWEEP and i > 0:
+                assert batches == [] or all(len(b.smp_times) == 1 for b in batches)
+            pool.absorb_pending()
+            batches += pool.take_done()
+            res = batches[-1].res
+        else:
+            res = R.satCalc(act, pool, worker, blocks[i], smp)
+        sw, sno, frames, co_ph, (cq, cl) = res[0]
+        where = f'block {i} (stream {first + i + 1})'
+        assert bool(sw) == bool(sw_ref), where
+        assert float(cq) == float(cq_ref) and float(cl) == float(cl_ref), where
+        assert len(frames) == len(fl_ref), where
+        assert bool(hc.PHASE_LOCKED) == bool(ss.phase_locked), where
+        assert hc.MS_TIME == ss.ms_time and len(hc.CORRLST) == len(ss.corrlst), where
+        if sw_ref:
+            assert float(hc.FREQ) == float(ss.freq), where          # a bin frequency of the sweep: exact
+        got.append(bool(sw))
+        if bool(sw) and not any(got[:-1]):                          # the trigger block itself
+            assert (first + i + 1) % 32 == 0, where
+            assert abs(float(hc.FREQ_SAVE) - float(ss.freq_save)) < 0.05, where
+            assert len(hc.DF_SAVE) == len(ss.df_save), where
+            np.testing.assert_allclose(hc.DF_SAVE, ss.df_save, atol=2e-3)
+            assert frames and frames[0]['SWP'] is False             # reported before the trigger (:1190-1203)
+    assert got.count(True) >= 2 and not got[0]                       # the sweep ran over several blocks
+    R.closeMultiProcPool(pool)
