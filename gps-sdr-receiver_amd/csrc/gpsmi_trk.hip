@@ -1430,7 +1430,14 @@ int gpsmi_trk_process_stream(gpsmi_trk* h, const void* iq, size_t n, gpsmi_trk_o
     if (!h->worker) {
         h->worker = new (std::nothrow) gpsmi_trk::StreamWorker();
         if (!h->worker) return fail(GPSMI_E_NOMEM, "out of host memory");
-        h->worker->th = std::thread(trk_worker_main, h);
+        try {
+            h->worker->th = std::thread(trk_worker_main, h);
+        } catch (...) {                     // (no thread to be had: nothing may be thrown across the ABI;
+            delete h->worker;               // the caller's thread makes the runtime calls itself)
+            h->worker = nullptr;
+            h->stream_thread = 0;
+            return trk_stream_step(h, iq, n, out);
+        }
     }
     gpsmi_trk::StreamWorker& w = *h->worker;
     std::unique_lock<std::mutex> lock(w.m);
