@@ -25,6 +25,7 @@
 //
 // Loop-carried state lives in device memory; the closed loop needs no host
 // round trip between blocks.
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
@@ -573,12 +574,18 @@ struct gpsmi_trk {
         long long submitted = 0;     // jobs handed over
         long long cleared = 0;       // jobs whose step before last has been seen complete (the caller may go on)
         long long finished = 0;      // jobs fully enqueued on the device
+        // the same three counters for the other thread to POLL before it goes to sleep on a condition
+        // variable: being woken from a futex measured 50-100 us on these hosts, three hand-overs per
+        // report block made gpsmi_trk_wait 290 us where the work outstanding was 60 us
+        std::atomic<long long> a_submitted{0}, a_cleared{0}, a_finished{0};
         int err = 0;
         char errmsg[512] = "";
     };
     StreamWorker* worker = nullptr;
     int stream_thread = 1;
     int stream_depth = 2;            // calls a streamed step's buffers stay in use: 2 (gpsmi.h) or 3
+    long long stat_backlog = 0;
+    long long stat_quiesce_ns = 0, stat_evwait_ns = 0, stat_waits = 0;   // gpsmi_trk_wait behind streamed steps
     long long stat_wait_ns = 0, stat_launch_ns = 0, stat_steps = 0;   // streamed steps: host time waiting for the
                                                                       // step before last / making the runtime calls
 };
@@ -632,7 +639,12 @@ static int trk_reserve(gpsmi_trk* h, size_t njobs) {
 // the three kernels over njobs jobs on the handle's stream, events around them
 static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
                       const gpsmi_trk_state* st_in, gpsmi_trk_state* st_out, const int* forced,
-                      int njobs, int nch, bool side_epilogue = false) {
+                      int njobs, int nch, bool side_epilogue = false, hipEvent_t tail_stop = nullptr,
+                      bool* tail_stop_used = nullptr) {
+    // tail_stop: an event to carry the completion signal of the launch's LAST kernel (the epilogue),
+    // instead of an event record behind it -- a record is a barrier packet, ~5 us of idle queue
+    // between this step and the next (the streamed closed loop: 32.5 -> 27 us per block);
+    // *tail_stop_used says whether the epilogue form at hand could take it
     TrkParams P = h->P;
     P.nch = nch;
     // the stream this launch goes to: the handle's, or ("corr_overlap") the slot's own, so that the
@@ -798,21 +810,40 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
         h->main_tail = sl.corr_done;          // (gpsmi_acq_after_trk orders the search behind this one)
         GPSMI_HIP(hipStreamWaitEvent(es, sl.corr_done, 0));
     }
+    const gpsmi_trk_state* c_in = st_in;
+    const JobMid* c_mid = sl.d_mid;
+    const float* c_rec = sl.d_rec;
+    const float2* c_partial = sl.d_partial;
+    bool stop_used = false;
+#define GPSMI_LAUNCH_EPI_SPAN(NCV)                                                                         \
+    do {                                                                                                  \
+        if (tail_stop) {                                                                                  \
+            hipExtLaunchKernelGGL(trk_epilogue_span_kernel<NCV>, dim3(njobs), dim3(256), 0, es, nullptr,  \
+                                  tail_stop, 0, c_in, st_out, c_mid, c_rec, ng_span, P, njobs, sl.d_out); \
+            stop_used = true;                                                                             \
+        } else {                                                                                          \
+            hipLaunchKernelGGL(trk_epilogue_span_kernel<NCV>, dim3(njobs), dim3(256), 0, es, c_in,        \
+                               st_out, c_mid, c_rec, ng_span, P, njobs, sl.d_out);                        \
+        }                                                                                                 \
+    } while (0)
     if (h->span8)
         hipLaunchKernelGGL(trk_epilogue_span8_kernel, dim3((njobs + 3) / 4), dim3(256), 0, es, st_in,
                            st_out, sl.d_mid, sl.d_rec, ng_span, P, njobs, sl.d_out);
     else if (span_single && P.n_cyc == 32)
-        hipLaunchKernelGGL(trk_epilogue_span_kernel<32>, dim3(njobs), dim3(256), 0, es, st_in, st_out,
-                           sl.d_mid, sl.d_rec, ng_span, P, njobs, sl.d_out);
+        GPSMI_LAUNCH_EPI_SPAN(32);
     else if (span_single && P.n_cyc == 16)
-        hipLaunchKernelGGL(trk_epilogue_span_kernel<16>, dim3(njobs), dim3(256), 0, es, st_in, st_out,
-                           sl.d_mid, sl.d_rec, ng_span, P, njobs, sl.d_out);
+        GPSMI_LAUNCH_EPI_SPAN(16);
     else if (span_single)
-        hipLaunchKernelGGL(trk_epilogue_span_kernel<8>, dim3(njobs), dim3(256), 0, es, st_in, st_out,
-                           sl.d_mid, sl.d_rec, ng_span, P, njobs, sl.d_out);
-    else
+        GPSMI_LAUNCH_EPI_SPAN(8);
+    else if (tail_stop) {
+        hipExtLaunchKernelGGL(trk_epilogue_kernel, dim3((njobs + 3) / 4), dim3(256), 0, es, nullptr, tail_stop,
+                              0, c_in, st_out, c_mid, c_partial, P, njobs, sl.d_out);
+        stop_used = true;
+    } else
         hipLaunchKernelGGL(trk_epilogue_kernel, dim3((njobs + 3) / 4), dim3(256), 0, es, st_in,
                            st_out, sl.d_mid, sl.d_partial, P, njobs, sl.d_out);
+#undef GPSMI_LAUNCH_EPI_SPAN
+    if (tail_stop_used) *tail_stop_used = stop_used;
     GPSMI_HIP(hipGetLastError());
     if (timed) GPSMI_HIP(hipEventRecord(sl.ev[3], es));
     if (side_epilogue) {
@@ -877,6 +908,32 @@ static int trk_pull_state(gpsmi_trk* h) {
 }
 
 // Is [p, p + bytes) page-locked host memory a kernel may address?  -> its device pointer.
+// Wait for an event the GPU is about to signal by POLLING it: hipEventSynchronize may put the thread
+// to sleep, and being woken by the driver measured ~250 us where the GPU had ~100 us of work left (the
+// drop-in path waits like this once a second of signal: 353 -> ~110 us per report block).  After 2 ms
+// the thread gives in and sleeps.
+// Poll `done()` for up to `us` microseconds (then the caller sleeps on its condition variable).
+template <class F>
+static void trk_spin_until(F&& done, int us) {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (!done()) {
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(us)) return;
+        __builtin_ia32_pause();
+    }
+}
+
+static hipError_t trk_spin_wait(hipEvent_t ev) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q != hipErrorNotReady) return q;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+        __builtin_ia32_pause();
+    }
+    (void)hipGetLastError();                // (hipErrorNotReady is sticky in the thread's last-error slot)
+    return hipEventSynchronize(ev);
+}
+
 // (memory from gpsmi_host_alloc is known without asking the runtime: hipPointerGetAttributes costs
 // ~2 us a call, twice per step)
 static bool trk_pinned_dev(gpsmi_trk* h, const void* p, size_t bytes, void** dev) {
@@ -907,6 +964,7 @@ static void trk_worker_cleared(gpsmi_trk* h) {
     {
         std::lock_guard<std::mutex> lock(w.m);
         w.cleared = w.finished + 1;             // (the job in hand)
+        w.a_cleared.store(w.cleared, std::memory_order_release);
     }
     w.cv_done.notify_all();
 }
@@ -916,6 +974,7 @@ static void trk_worker_main(gpsmi_trk* h) {
     (void)hipSetDevice(h->cfg.device);
     for (;;) {
         gpsmi_trk::StreamJob job;
+        trk_spin_until([&] { return w.a_submitted.load(std::memory_order_acquire) > w.a_finished.load(std::memory_order_relaxed); }, 300);
         {
             std::unique_lock<std::mutex> lock(w.m);
             w.cv_job.wait(lock, [&] { return w.stop || !w.q.empty(); });
@@ -932,6 +991,8 @@ static void trk_worker_main(gpsmi_trk* h) {
             w.q.pop_front();
             w.finished += 1;
             if (w.cleared < w.finished) w.cleared = w.finished;
+            w.a_cleared.store(w.cleared, std::memory_order_release);
+            w.a_finished.store(w.finished, std::memory_order_release);
         }
         w.cv_done.notify_all();
     }
@@ -942,6 +1003,7 @@ static void trk_worker_main(gpsmi_trk* h) {
 static int trk_quiesce(gpsmi_trk* h) {
     if (!h || !h->worker) return GPSMI_OK;
     gpsmi_trk::StreamWorker& w = *h->worker;
+    trk_spin_until([&] { return w.a_finished.load(std::memory_order_acquire) == w.a_submitted.load(std::memory_order_relaxed); }, 1000);
     std::unique_lock<std::mutex> lock(w.m);
     w.cv_done.wait(lock, [&] { return w.finished == w.submitted; });
     if (w.err) {
@@ -1326,7 +1388,7 @@ static int trk_stream_step(gpsmi_trk* h, const void* iq, size_t n, gpsmi_trk_out
         for (int k = 0; k < 2; ++k) {
             GPSMI_HIP(hipEventCreateWithFlags(&h->up_done[k], hipEventDisableTiming));
             GPSMI_HIP(hipEventCreateWithFlags(&h->stage_free[k], hipEventDisableTiming));
-            GPSMI_HIP(hipEventCreateWithFlags(&h->in_done[k], hipEventDisableTiming));
+            GPSMI_HIP(hipEventCreate(&h->in_done[k]));       // (also a dispatch's stop event)
         }
     }
     if (bytes > h->stage_bytes) {
@@ -1355,7 +1417,7 @@ static int trk_stream_step(gpsmi_trk* h, const void* iq, size_t n, gpsmi_trk_out
     // steps ahead of the device, which keeps one whole step queued behind the one that is running
     const auto t_w0 = std::chrono::steady_clock::now();
     if (h->in_pending[s]) {
-        GPSMI_HIP(hipEventSynchronize(h->in_done[s]));
+        GPSMI_HIP(trk_spin_wait(h->in_done[s]));
         h->in_pending[s] = false;
     }
     const auto t_w1 = std::chrono::steady_clock::now();
@@ -1398,7 +1460,12 @@ static int trk_stream_step(gpsmi_trk* h, const void* iq, size_t n, gpsmi_trk_out
     h->timing = 0;                          // (no kernel-timing events in a streaming loop)
     gpsmi_trk_out* const d_out_keep = sl.d_out;
     if (out_direct) sl.d_out = static_cast<gpsmi_trk_out*>(out_dev);
-    rc = trk_launch(h, sl, h->d_stage[s], h->d_state, h->d_state, nullptr, h->rows(), h->max_ch);
+    // the step's completion event = the completion signal of its last kernel, when nothing is
+    // queued behind that kernel (no record copy, no upload-stream bookkeeping)
+    const bool want_tail = in_line && (!out || out_direct);
+    bool tail_used = false;
+    rc = trk_launch(h, sl, h->d_stage[s], h->d_state, h->d_state, nullptr, h->rows(), h->max_ch,
+                    /*side_epilogue=*/false, want_tail ? h->in_done[s] : nullptr, &tail_used);
     sl.d_out = d_out_keep;
     h->timing = timing;
     if (rc) return rc;
@@ -1411,7 +1478,7 @@ static int trk_stream_step(gpsmi_trk* h, const void* iq, size_t n, gpsmi_trk_out
     if (out && !out_direct)
         GPSMI_HIP(hipMemcpyAsync(out, sl.d_out, h->rows() * sizeof(gpsmi_trk_out),
                                  hipMemcpyDeviceToHost, h->stream));
-    GPSMI_HIP(hipEventRecord(h->in_done[s], h->stream));
+    if (!tail_used) GPSMI_HIP(hipEventRecord(h->in_done[s], h->stream));
     h->in_pending[s] = true;
     h->stat_launch_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_w1).count();
     h->stat_steps += 1;
@@ -1449,12 +1516,18 @@ int gpsmi_trk_process_stream(gpsmi_trk* h, const void* iq, size_t n, gpsmi_trk_o
     }
     w.q.push_back({iq, n, out});
     const long long k = ++w.submitted;          // this job's ordinal, from 1
+    w.a_submitted.store(k, std::memory_order_release);
     w.cv_job.notify_one();
     // the contract of gpsmi.h: return once the step of the call before last is complete -- the
     // submission thread says so when it has waited for that step on its way into this one
     // ("stream_depth" = 3: one step more -- the call returns when the step three calls back is
     // complete, so the caller can hand over its next block while this one is still being enqueued)
     const long long need = k - (h->stream_depth - 2);
+    if (w.cleared < need) {
+        lock.unlock();
+        trk_spin_until([&] { return w.a_cleared.load(std::memory_order_acquire) >= need; }, 300);
+        lock.lock();
+    }
     w.cv_done.wait(lock, [&] { return w.cleared >= need; });
     return GPSMI_OK;
 }
@@ -1540,7 +1613,11 @@ int gpsmi_trk_replay_run_async(gpsmi_trk* h, const void* d_iq, int nb) {
 
 int gpsmi_trk_wait(gpsmi_trk* h) {
     GPSMI_REQUIRE(h, "null handle");
+    const auto t_q0 = std::chrono::steady_clock::now();
+    if (h->worker) h->stat_backlog += h->worker->a_submitted.load() - h->worker->a_finished.load();
     GPSMI_QUIESCE(h);
+    const auto t_q1 = std::chrono::steady_clock::now();
+    h->stat_quiesce_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(t_q1 - t_q0).count();
     GPSMI_HIP(hipSetDevice(h->cfg.device));
     // only streamed steps outstanding (in line on the main stream): the event behind the latest one
     // covers everything, and waiting for an event returns ~100 us sooner than the three stream
@@ -1550,8 +1627,10 @@ int gpsmi_trk_wait(gpsmi_trk* h) {
     if (!replay_busy && !h->stage_used[0] && !h->stage_used[1] && (h->in_pending[0] || h->in_pending[1])) {
         const int latest = h->stage_idx ^ 1;               // (the slot of the step enqueued last)
         if (h->in_pending[latest]) {
-            GPSMI_HIP(hipEventSynchronize(h->in_done[latest]));
+            GPSMI_HIP(trk_spin_wait(h->in_done[latest]));
             h->in_pending[0] = h->in_pending[1] = false;
+            h->stat_evwait_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_q1).count();
+            h->stat_waits += 1;
             return GPSMI_OK;
         }
     }
@@ -1753,6 +1832,11 @@ int gpsmi_trk_get_option(gpsmi_trk* h, const char* key, long long* value) {
     else if (!strcmp(key, "stream_thread")) *value = h->stream_thread;
     else if (!strcmp(key, "stream_depth")) *value = h->stream_depth;
     else if (!strcmp(key, "stat_stream_steps")) *value = h->stat_steps;
+    else if (!strcmp(key, "stat_waits")) *value = h->stat_waits;
+    else if (!strcmp(key, "stat_backlog")) *value = h->stat_backlog;
+
+    else if (!strcmp(key, "stat_quiesce_ns")) *value = h->stat_quiesce_ns;
+    else if (!strcmp(key, "stat_evwait_ns")) *value = h->stat_evwait_ns;
     else if (!strcmp(key, "stat_stream_wait_ns")) *value = h->stat_wait_ns;
     else if (!strcmp(key, "stat_stream_launch_ns")) *value = h->stat_launch_ns;
     else if (!strcmp(key, "correlator")) *value = (h->mfma == 4 || h->span8) ? 1 : 0;     // what runs, not what was asked

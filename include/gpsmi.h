@@ -91,6 +91,9 @@ int gpsmi_abi_sizeof(int which);
  *   "stream_thread"     1 (default): the launches of a gpsmi_trk_process_stream step are made by a
  *                       submission thread of the handle while the caller prepares its next block
  *                       (they cost as much host time as the step takes on the GPU); 0: by the caller
+ *   "stat_*"            (get only) counters of the streamed path, for tools/feed_split.py: steps, the
+ *                       submission thread's time waiting for the step before last / making the runtime
+ *                       calls, and gpsmi_trk_wait's time waiting for that thread / for the device
  *   "stream_depth"      2 (default): gpsmi_trk_process_stream returns once the step of the call
  *                       BEFORE LAST is complete (three caller buffers in rotation); 3: the step three
  *                       calls back (four buffers) -- with the submission thread the caller then hands
