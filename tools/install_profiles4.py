@@ -14,7 +14,8 @@ names = {'bench_line.json': 'bench_line.json', 'bench_prof_line.json': 'bench_li
          'acq_bench.txt': 'acq_bench.txt', 'batched_bench.txt': 'batched_bench.txt',
          'stream_bench.txt': 'stream_bench.txt', 'cfg5_kernel_table.md': 'cfg5_kernel_table.md',
          'cfg5_line.json': 'cfg5_line.json', 'clock_settling.txt': 'clock_settling.txt',
-         'chain_floor.txt': 'chain_floor.txt', 'feed_trace_summary.txt': 'dropin_feed_trace.txt', 'dropin_profile.txt': 'dropin_profile.txt'}
+         'chain_floor.txt': 'chain_floor.txt', 'feed_trace_summary.txt': 'dropin_feed_trace.txt', 'dropin_profile.txt': 'dropin_profile.txt', 'feed_split.txt': 'dropin_feed_split.txt',
+         'feed_trace_report_block.txt': 'dropin_feed_trace_report_block.txt'}
 for src, dst in names.items():
     if os.path.exists(R + src):
         shutil.copy(R + src, P + dst)
