@@ -728,7 +728,7 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
     bool corr_done_recorded = false;
     // batch form of the span correlator: persistent workgroups, two per CU, an equal number of
     // (block, channel group) units each
-    const int span_units = nblocks * ng_span, span_slots = (P.n_cyc == 32 ? 2 : 3) * h->n_cu;   // (kSpWgPerCu)
+    const int span_units = nblocks * ng_span, span_slots = sp_wg_per_cu(P.n_cyc) * h->n_cu;
     const int span_per = (span_units + span_slots - 1) / span_slots;
     const dim3 span_grid((span_units + span_per - 1) / (span_per > 0 ? span_per : 1));
     if (timed && !ext_timed) GPSMI_HIP(hipEventRecord(sl.ev[1], rs));

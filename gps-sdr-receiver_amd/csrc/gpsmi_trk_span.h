@@ -285,6 +285,30 @@ __device__ __forceinline__ void sp_rec3(sp2 nk, sp2& u1, sp2& d1, sp2& u2, sp2& 
         : "v"(nk));
 }
 
+// The same for the stacked form of eight-row blocks (below): TWO components, B = replica * (z.re | z.im)
+__device__ __forceinline__ void sp_b2(sp2 cd, sp2 nk, sp2& u1, sp2& d1, sp2& u2, sp2& d2, sp2& b1, sp2& b2) {
+    asm("v_pk_mul_f32 %0, %6, %2\n\t"
+        "v_pk_mul_f32 %1, %6, %4\n\t"
+        "v_pk_fma_f32 %3, %7, %2, %3\n\t"
+        "v_pk_fma_f32 %5, %7, %4, %5\n\t"
+        "v_pk_add_f32 %2, %2, %3\n\t"
+        "v_pk_add_f32 %4, %4, %5"
+        : "=&v"(b1), "=&v"(b2), "+v"(u1), "+v"(d1), "+v"(u2), "+v"(d2)
+        : "v"(cd), "v"(nk));
+}
+__device__ __forceinline__ void sp_rec2(sp2 nk, sp2& u1, sp2& d1, sp2& u2, sp2& d2) {
+    asm("v_pk_fma_f32 %1, %4, %0, %1\n\t"
+        "v_pk_fma_f32 %3, %4, %2, %3\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_add_f32 %2, %2, %3"
+        : "+v"(u1), "+v"(d1), "+v"(u2), "+v"(d2)
+        : "v"(nk));
+}
+// the value the lane 32 away holds (the other half of the M tile's row groups)
+__device__ __forceinline__ sp4 sp_swap32(sp4 v) {
+    return sp4{__shfl_xor(v[0], 32, 64), __shfl_xor(v[1], 32, 64), __shfl_xor(v[2], 32, 64), __shfl_xor(v[3], 32, 64)};
+}
+
 // One wave: NSPANS consecutive spans starting at position `pos0` (a multiple of 64) of a
 // block.  The caller has requested the first tile into `st` (sp_load_tile) and fetched the
 // descriptor; on return `st` holds the request for the tile at `next_pos` of `next_blk` (the
@@ -306,6 +330,13 @@ __device__ __forceinline__ void span_wave(const void* __restrict__ blk, const vo
                                           Close&& close, Hook&& after_first_swap) {
     constexpr int CS = kFftN;
     constexpr int MT = (NC + 15) / 16;                           // M tiles of 16 rows
+    // EIGHT rows: the M tile is stacked, rows 0..7 = Re x of the block's rows, rows 8..15 = Im x, and a
+    // K-step is TWO real products with B = replica * z.re and replica * z.im (x = a + j b, B = c + j d:
+    // the first gives (a c ; b c), the second (a d ; b d)); re = a c - b d and im = a d + b c pair a
+    // value of lanes 0..31 (row groups 0, 1: the a rows) with one of lanes 32..63 (the b rows): one
+    // exchange per span.  Every row of M works (the three-product form would leave half of them empty:
+    // 0.182 ms per 512 MiB, 37 % of the HBM peak), two recurrences instead of three, no a + b.
+    constexpr bool kStack = NC == 8;
     const int k = lane >> 4;
     const int q0 = pos0 & ~(kSpQuarter - 1);                      // start of the quarter
     constexpr int kTiles = NSPANS;
@@ -328,11 +359,17 @@ __device__ __forceinline__ void span_wave(const void* __restrict__ blk, const vo
         const float2 dz0 = sp_cmul(z0, omw8), dz1 = sp_cmul(z1, omw8);   // z(m) - z(m - 8)
         const float on = active ? 1.f : 0.f;
         u1 = sp2{on * z0.x, on * z1.x};
-        u2 = sp2{on * (z0.y - z0.x), on * (z1.y - z1.x)};
-        u3 = sp2{on * (z0.x + z0.y), on * (z1.x + z1.y)};
         d1 = sp2{on * dz0.x, on * dz1.x};
-        d2 = sp2{on * (dz0.y - dz0.x), on * (dz1.y - dz1.x)};
-        d3 = sp2{on * (dz0.x + dz0.y), on * (dz1.x + dz1.y)};
+        if (kStack) {
+            u2 = sp2{on * z0.y, on * z1.y};
+            d2 = sp2{on * dz0.y, on * dz1.y};
+            u3 = sp2{0.f, 0.f}; d3 = u3;
+        } else {
+            u2 = sp2{on * (z0.y - z0.x), on * (z1.y - z1.x)};
+            u3 = sp2{on * (z0.x + z0.y), on * (z1.x + z1.y)};
+            d2 = sp2{on * (dz0.y - dz0.x), on * (dz1.y - dz1.x)};
+            d3 = sp2{on * (dz0.x + dz0.y), on * (dz1.x + dz1.y)};
+        }
         nk = sp2{nkv, nkv};
     }
     const int d_c = active ? cmd.delay_used : 0;
@@ -344,7 +381,10 @@ __device__ __forceinline__ void span_wave(const void* __restrict__ blk, const vo
     const int rel0 = pos0 - q0;                                        // range start within the quarter
     // a range that starts inside the quarter: the recurrence steps of the positions before it
 #pragma unroll 1
-    for (int s = 0; s < rel0 / 8; ++s) sp_rec3(nk, u1, d1, u2, d2, u3, d3);
+    for (int s = 0; s < rel0 / 8; ++s) {
+        if (kStack) sp_rec2(nk, u1, d1, u2, d2);
+        else sp_rec3(nk, u1, d1, u2, d2, u3, d3);
+    }
 
     // ---- replica: position m = 4 s + k of the tile, rolled index r = (m - d) mod 2048 = 4 h + e
     // with e = (pos0 + k - d) & 3 fixed for the lane and h advancing by one per K-step: a
@@ -353,6 +393,10 @@ __device__ __forceinline__ void span_wave(const void* __restrict__ blk, const vo
     // at the top of a tile, IN FRONT of the row requests: loads return in order, so a wait for
     // entries (or for the registers they land in) never waits for rows.  The second half of the
     // tile goes straight to its place, the first half of the NEXT tile to a side buffer.
+    // (The entries are float32, not signs: GPSCacode interpolates between chips, gpslib.py:62-77 --
+    // 489 distinct values per replica.  A table of sign bits, tried in round 4, would take these loads
+    // out of the tile loop -- 64 lanes in 64 different cache lines, four times per tile -- but not
+    // reproduce the reference's replica.)
     const __amdgpu_buffer_rsrc_t code_rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(code_q4), 0, (GPSMI_MAX_PRN + 1) * 2 * CS * (int)sizeof(float), kRsrcFlags);
     int cd_off;
@@ -377,11 +421,14 @@ __device__ __forceinline__ void span_wave(const void* __restrict__ blk, const vo
         k1[mt] = zero4; k2[mt] = zero4; k3[mt] = zero4;
         tot[mt][0] = zero4; tot[mt][1] = zero4;
     }
+    // (re, im) of what the accumulators hold
+    auto acc_re = [&](int mt) -> sp4 { return kStack ? k1[mt] - sp_swap32(k2[mt]) : k1[mt] - k3[mt]; };
+    auto acc_im = [&](int mt) -> sp4 { return kStack ? k2[mt] + sp_swap32(k1[mt]) : k1[mt] + k2[mt]; };
     // the lanes of a channel close its lo sum where the boundary passes
     auto close_lo = [&]() {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            close(mt, tot[mt][0] + (k1[mt] - k3[mt]), tot[mt][1] + (k1[mt] + k2[mt]));
+            close(mt, tot[mt][0] + acc_re(mt), tot[mt][1] + acc_im(mt));
             tot[mt][0] = zero4; tot[mt][1] = zero4;
             k1[mt] = zero4; k2[mt] = zero4; k3[mt] = zero4;
         }
@@ -402,7 +449,9 @@ __device__ __forceinline__ void span_wave(const void* __restrict__ blk, const vo
     // lane = (row, k) reads the sample at position 4 s + k of its row: 8 bytes.  Pairs 8 .. 15 and
     // 24 .. 31 of a complex64 tile sit with their two positions swapped in LDS (sp_store_tile):
     // K-steps 4 .. 7 and 12 .. 15 read the other half of their 16-byte piece
-    const float* ap = tl + (lane & 15) * kSpRowDw + 2 * k;
+    // (stacked form: row = lane % 8, component = (lane / 8) % 2: one float)
+    const float* ap = kStack ? tl + (lane & 7) * kSpRowDw + 2 * k + ((lane >> 3) & 1)
+                             : tl + (lane & 15) * kSpRowDw + 2 * k;
     const int swz_ofs = FMT == 0 ? ((k & 1) ? -2 : 2) : 0;
 
     // operands of one K-step (four positions): the lane's sample of both row halves and re + im
@@ -410,11 +459,17 @@ __device__ __forceinline__ void span_wave(const void* __restrict__ blk, const vo
     auto read_ops = [&](int s) {                                     // s: K-step index in the tile
         Ops o;
         const float* p = ap + (((s >> 2) & 1) ? swz_ofs : 0) + 8 * s;
+        if (kStack) {
+            o.xs[0] = *p;
+            o.x[0] = sp2{0.f, 0.f};
+            return o;
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) o.x[mt] = *reinterpret_cast<const sp2*>(p + mt * 16 * kSpRowDw);
         return o;
     };
     auto sums = [&](Ops& o) {
+        if (kStack) return;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) o.xs[mt] = o.x[mt].x + o.x[mt].y;
     };
@@ -424,6 +479,11 @@ __device__ __forceinline__ void span_wave(const void* __restrict__ blk, const vo
     };
     // one K-step: six MFMAs (first: C = 0, an inline constant, no zeroing of the accumulators)
     auto kstep = [&](const Ops& o, float b1, float b2, float b3, auto first) {
+        if (kStack) {                                    // two products on the stacked tile
+            k1[0] = mfma(o.xs[0], b1, decltype(first)::value ? zero4 : k1[0]);
+            k2[0] = mfma(o.xs[0], b2, decltype(first)::value ? zero4 : k2[0]);
+            return;
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             k1[mt] = mfma(o.xs[mt], b1, decltype(first)::value ? zero4 : k1[mt]);
@@ -488,14 +548,17 @@ __device__ __forceinline__ void span_wave(const void* __restrict__ blk, const vo
             }
             Ops o[2];
             o[0] = read_ops(8 * hw);
-            sp2 b1, b2, b3;
+            sp2 b1, b2, b3 = sp2{0.f, 0.f};
             if (fast) {
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
                     if (s + 1 < 8) o[(s + 1) & 1] = read_ops(8 * hw + s + 1);
                     __builtin_amdgcn_sched_barrier(0);
                     sums(o[s & 1]);
-                    if (!(s & 1)) sp_b3(cd_pair(8 * hw + s), nk, u1, d1, u2, d2, u3, d3, b1, b2, b3);
+                    if (!(s & 1)) {
+                        if (kStack) sp_b2(cd_pair(8 * hw + s), nk, u1, d1, u2, d2, b1, b2);
+                        else sp_b3(cd_pair(8 * hw + s), nk, u1, d1, u2, d2, u3, d3, b1, b2, b3);
+                    }
                     const float c1 = (s & 1) ? b1.y : b1.x, c2 = (s & 1) ? b2.y : b2.x, c3 = (s & 1) ? b3.y : b3.x;
                     if (s == 0) kstep(o[0], c1, c2, c3, first);
                     else kstep(o[s & 1], c1, c2, c3, std::false_type{});
@@ -514,7 +577,11 @@ __device__ __forceinline__ void span_wave(const void* __restrict__ blk, const vo
                         if (j + 1 < 4 || g == 0) o[(j + 1) & 1] = read_ops(s0 + j + 1);
                         __builtin_amdgcn_sched_barrier(0);
                         sums(o[j & 1]);
-                        if (!(j & 1)) sp_b3(j == 0 ? sp2{v.x, v.y} : sp2{v.z, v.w}, nk, u1, d1, u2, d2, u3, d3, b1, b2, b3);
+                        if (!(j & 1)) {
+                            const sp2 cdv = j == 0 ? sp2{v.x, v.y} : sp2{v.z, v.w};
+                            if (kStack) sp_b2(cdv, nk, u1, d1, u2, d2, b1, b2);
+                            else sp_b3(cdv, nk, u1, d1, u2, d2, u3, d3, b1, b2, b3);
+                        }
                         const float c1 = (j & 1) ? b1.y : b1.x, c2 = (j & 1) ? b2.y : b2.x, c3 = (j & 1) ? b3.y : b3.x;
                         if (nb >= tpos + 4 * (s0 + j + 1)) kstep(o[j & 1], c1, c2, c3, std::false_type{});
                         else kstep_checked(o[j & 1], s0 + j, c1, c2, c3);
@@ -527,8 +594,8 @@ __device__ __forceinline__ void span_wave(const void* __restrict__ blk, const vo
         // a span ends (its accumulators restart from C = 0 at the next span)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            tot[mt][0] = tot[mt][0] + (k1[mt] - k3[mt]);
-            tot[mt][1] = tot[mt][1] + (k1[mt] + k2[mt]);
+            tot[mt][0] = tot[mt][0] + acc_re(mt);
+            tot[mt][1] = tot[mt][1] + acc_im(mt);
         }
         cd[0] = cdn[0]; cd[1] = cdn[1];
         if (tix + 1 < kTiles) enter_tile(tix + 1);
@@ -569,12 +636,13 @@ constexpr int kSpLoOfs = 16 * 64;                      // lo_fin within it
 
 // (FMT 1: iq holds raw uint16 samples, 2 bytes each, decoded on the way into LDS)
 // workgroups per CU the registers admit: two M tiles = 250 VGPRs, one = 168
-template <int NC> constexpr int kSpWgPerCu = NC == 32 ? 2 : 3;
+// (eight rows, stacked form: 122, four workgroups)
+constexpr __host__ __device__ int sp_wg_per_cu(int nc) { return nc == 32 ? 2 : (nc == 16 ? 3 : 4); }
 // a wave's tile area: NC rows (16 at least: the A operand's lanes address rows 0..15)
 template <int NC> constexpr int kSpAreaFloats = (NC < 16 ? 16 : NC) * kSpRowDw;
 
 template <int NSPANS, int WAVES, int FMT = 0, int DIAG = 0, int NC = 32>
-__global__ __launch_bounds__(64 * WAVES, kSpWgPerCu<NC>) void trk_span_kernel(
+__global__ __launch_bounds__(64 * WAVES, sp_wg_per_cu(NC)) void trk_span_kernel(
     const void* __restrict__ iq_v, const JobMid* __restrict__ mid,
     const float* __restrict__ code_eo, TrkParams P, int ngroups, int nblocks,
     float* __restrict__ rec, float2* __restrict__ partial) {

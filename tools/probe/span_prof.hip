@@ -4,7 +4,9 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Igps-sdr-receiver_amd/csrc \
 //         tools/probe/span_prof.hip gps-sdr-receiver_amd/csrc/gpsmi_core.hip \
 //         gps-sdr-receiver_amd/csrc/gpsmi_acq.hip -o tools/probe/span_prof
-//   tools/probe/span_prof [blocks = 1024]
+//   tools/probe/span_prof [blocks = 1024] [workgroup slots = 512]
+// With -DPROBE_NC=16 or 8: the batch form for blocks of that many rows (no checks: the tests have them;
+// timings, diagnostics and stamps only; slots = 768 / 1024).
 // With -DGPSMI_SPAN_STAMPS (-o tools/probe/span_stamps): the checks, then the 100 MHz phase stamps of
 // one launch of the batch form (where a unit's time goes besides its tile loop) and nothing else.
 #include "../../gps-sdr-receiver_amd/csrc/gpsmi_trk.hip"
@@ -18,6 +20,9 @@
 #include <cstring>
 
 using namespace gpsmi;
+#ifndef PROBE_NC
+#define PROBE_NC 32
+#endif
 
 // naive reference of partial[(b, c, o)], o = q + 1: window q = positions m >= d of row q plus
 // m < d of row q + 1 of  replica[(m - d) mod CS] x[r][m] exp(-j (ph + om (r CS + m + 1) / fs))
@@ -70,14 +75,14 @@ static unsigned long long* g_stamp_buf;
 template <int NSP, int WAVES, int DIAG>
 static void launch_span_t(const Bufs& B, int nblocks, int nch, bool collect) {
     TrkParams P{};
-    P.cs = 2048; P.n_cyc = 32; P.nch = nch;
+    P.cs = 2048; P.n_cyc = PROBE_NC; P.nch = nch;
     const int ng = (nch + kSpCh - 1) / kSpCh;
     int grid = nblocks * ng * (32 / NSP) / WAVES;
     if (NSP * WAVES == 32) {                       // batch form: persistent workgroups, two per CU
         const int per = (grid + g_slots - 1) / g_slots;
         grid = (grid + per - 1) / per;
     }
-    hipLaunchKernelGGL((trk_span_kernel<NSP, WAVES, 0, DIAG>), dim3(grid), dim3(64 * WAVES), 0, 0, B.iq, B.mid,
+    hipLaunchKernelGGL((trk_span_kernel<NSP, WAVES, 0, DIAG, PROBE_NC>), dim3(grid), dim3(64 * WAVES), 0, 0, B.iq, B.mid,
                        B.code_eo, P, ng, nblocks, B.rec, B.partial);
     if (collect && NSP * WAVES != 32)
         hipLaunchKernelGGL(collect_kernel<NSP>, dim3((nblocks * nch + 3) / 4), dim3(256), 0, 0, B.rec, B.mid, ng,
@@ -141,7 +146,7 @@ static void timeit(const char* name, F launch, const Bufs& B, int nblocks, int n
         float ms; hipEventElapsedTime(&ms, e0, e1); ms /= per;
         best = std::min(best, ms); sum += ms;
     }
-    const double gb = (double)nblocks * 65536 * 8 / 1e9;
+    const double gb = (double)nblocks * 2048 * PROBE_NC * 8 / 1e9;
     printf("time  %-12s %4d blocks x %2d ch: %.4f ms mean, %.4f best of %d x %d back-to-back launches: "
            "%.0f GB/s (%.1f %% of 8 TB/s)\n", name, nblocks, nch, sum / reps, best, reps, per,
            gb / (sum / reps) * 1e3, gb / (sum / reps) * 1e3 / 80.0);
@@ -225,7 +230,7 @@ static void set_delays(Bufs& B, int nblocks, int nch, int mode) {
 int main(int argc, char** argv) {
     const int nblocks = argc > 1 ? atoi(argv[1]) : 1024, nch = 12;
     if (argc > 2) g_slots = atoi(argv[2]);
-    const size_t blk = (size_t)2048 * 32;
+    const size_t blk = (size_t)2048 * PROBE_NC;
     Bufs B{};
     hipMalloc((void**)&B.iq, nblocks * blk * sizeof(float2));
     {
@@ -274,7 +279,7 @@ int main(int argc, char** argv) {
 #endif
 
     const int ncheck = std::min(nblocks, 24);   // (<= 32: the record buffer holds 32 x 32 records)
-    for (int mode = 0; mode < 4; ++mode) {
+    for (int mode = 0; mode < (PROBE_NC == 32 ? 4 : 0); ++mode) {
         set_delays(B, nblocks, nch, mode);
         printf("-- delays: %s\n", mode == 0 ? "spread" : mode == 1 ? "edges" : mode == 2 ? "one quarter" : "random, some closed");
         check("mfma<4>", launch_mfma, B, ncheck, nch);
@@ -347,6 +352,32 @@ int main(int argc, char** argv) {
         return 0;
     }
 #endif
+    if (PROBE_NC != 32) {
+        set_delays(B, nblocks, nch, 0);
+        printf("-- %d rows per block; diagnostics (delays spread): 1 no MFMAs, 2 no row loads after the first tile, "
+               "4 no barrier / combine\n", PROBE_NC);
+        for (int r = 0; r < 2; ++r) {
+            timeit("span", launch_span, B, nblocks, nch);
+            timeit("span diag 1", launch_span_diag<1>, B, nblocks, nch);
+            timeit("span diag 2", launch_span_diag<2>, B, nblocks, nch);
+            timeit("span diag 3", launch_span_diag<3>, B, nblocks, nch);
+            timeit("span diag 4", launch_span_diag<4>, B, nblocks, nch);
+            timeit("span diag 5", launch_span_diag<5>, B, nblocks, nch);
+            timeit("span diag 6", launch_span_diag<6>, B, nblocks, nch);
+            timeit("span diag 7", launch_span_diag<7>, B, nblocks, nch);
+        }
+        std::vector<JobMid> mid((size_t)nblocks * nch);
+        hipMemcpy(mid.data(), B.mid, mid.size() * sizeof(JobMid), hipMemcpyDeviceToHost);
+        for (auto& m : mid) m.delay_used = 0;
+        hipMemcpy(B.mid, mid.data(), mid.size() * sizeof(JobMid), hipMemcpyHostToDevice);
+        printf("-- every delay 0 (no boundary tiles)\n");
+        timeit("span", launch_span, B, nblocks, nch);
+        timeit("span diag 1", launch_span_diag<1>, B, nblocks, nch);
+        timeit("span diag 2", launch_span_diag<2>, B, nblocks, nch);
+        timeit("span diag 3", launch_span_diag<3>, B, nblocks, nch);
+        timeit("span diag 7", launch_span_diag<7>, B, nblocks, nch);
+        return 0;
+    }
     for (int mode : {0, 2}) {
         set_delays(B, nblocks, nch, mode);
         printf("-- delays: %s\n", mode == 0 ? "spread" : "one quarter");
