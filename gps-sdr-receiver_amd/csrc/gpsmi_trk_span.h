@@ -52,11 +52,11 @@
 //
 // Other block lengths (gpsglob.py:122-124: N_CYC "currently possible are (32,16,8)").  NC = 16 is ONE M
 // tile (MT = 1) of the same scheme: tiles of 16 rows x 64 positions (8 KiB, eight loads per lane), half the
-// MFMAs per tile and the same B arithmetic, 168 VGPRs -> three workgroups per CU.  NC = 8 runs the same
-// code with half of the M tile empty (rows 8..15 of A are whatever the tile area holds: row r of D depends
-// on row r of A alone and nobody reads those rows); it beats the vector kernel (23 % of the HBM peak) by
-// a little and shares every line with the other two.  The summation order is unchanged, so the
-// single-block form and the batch form stay bytewise equal for every NC.
+// MFMAs per tile and the same B arithmetic, 155 VGPRs -> three workgroups per CU.  NC = 8 stacks the M
+// tile: rows 0..7 = Re x, rows 8..15 = Im x of the block's eight rows, TWO real products per K-step
+// (B = replica * z.re, replica * z.im), re / im paired across the two lane halves once per span (kStack in
+// span_wave), 122 VGPRs -> four workgroups per CU.  The order of the sums within a form is a property
+// of the data, so the single-block form and the batch form stay bytewise equal for every NC.
 #pragma once
 #include <hip/hip_runtime.h>
 
