@@ -37,6 +37,7 @@ static OptDef g_opts[] = {
     {"corr_small2", nullptr, false, 0},
     {"span_single_max", "GPSMI_SPAN_SINGLE_MAX", false, 0},
     {"stream_inline_max", "GPSMI_STREAM_INLINE_MAX", false, 0},
+    {"stream_direct_max", "GPSMI_STREAM_DIRECT_MAX", false, 0},
     {"done_by_dispatch", "GPSMI_DONE_BY_DISPATCH", false, 0},
     {"corr_overlap", "GPSMI_CORR_OVERLAP", false, 0},
     {"stream_thread", "GPSMI_STREAM_THREAD", false, 0},

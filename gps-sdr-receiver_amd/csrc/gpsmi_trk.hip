@@ -492,6 +492,8 @@ struct gpsmi_trk {
     bool stage_used[2] = {false, false};
     int stage_idx = 0;
     size_t stream_inline_max = 8u << 20;     // bytes up to which a streamed block is copied on the main stream
+    size_t stream_direct_max = 0;            // bytes up to which the kernels of a streamed step read a page-locked
+                                             // block where it lies (no staging copy): option "stream_direct_max"
                                              // (GPSMI_STREAM_INLINE_MAX)
     hipEvent_t order = nullptr;          // orders other handles' streams behind this one
     hipEvent_t main_tail = nullptr;      // the event recorded behind the last work on `stream`, if any
@@ -1151,6 +1153,7 @@ static int trk_build(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk* h) {
     P.flags = (int)v;
     const struct { const char* key; long long fallback; } tun[] = {
         {"corr_cg", h->corr_cg}, {"span_single_max", h->span_single_max}, {"stream_inline_max", (long long)h->stream_inline_max},
+        {"stream_direct_max", (long long)h->stream_direct_max},
         {"done_by_dispatch", h->done_by_dispatch}, {"corr_overlap", h->corr_overlap},
         {"stream_thread", h->stream_thread}, {"stream_depth", h->stream_depth}, {"fold_chunk", h->fold_chunk}};
     for (const auto& t : tun) {
@@ -1438,10 +1441,17 @@ static int trk_stream_step(gpsmi_trk* h, const void* iq, size_t n, gpsmi_trk_out
     // 50 against 58 us for eight; equal at 64).  Beyond that it goes up on the upload stream under the
     // previous step's kernels, as soon as the kernels that read this staging block two calls ago have
     // finished.  Either way the host never waits.
-    const bool in_line = pinned && bytes <= h->stream_inline_max;
+    // Small steps need no staging at all: the tracking kernels read the page-locked block over PCIe where it
+    // lies (each sample is read once by the correlator and one row of it by the code-phase correlation), which
+    // takes the copy kernel, its launch and the kernel boundary behind it out of the step.  The block
+    // stays the caller's until the step is complete, as the contract of gpsmi.h says anyway.
+    const bool direct_in = pinned && bytes <= h->stream_direct_max;
+    const bool in_line = pinned && (direct_in || bytes <= h->stream_inline_max);
     hipStream_t us = in_line ? h->stream : h->up_stream;
     if (!in_line && h->stage_used[s]) GPSMI_HIP(hipStreamWaitEvent(h->up_stream, h->stage_free[s], 0));
-    if (pinned) {
+    if (direct_in) {
+        // (nothing to move)
+    } else if (pinned) {
         const size_t n16 = bytes / 16;
         const unsigned grid = (unsigned)((n16 + 255) / 256 < 512 ? (n16 + 255) / 256 : 512);
         hipLaunchKernelGGL(stage_copy_kernel, dim3(grid), dim3(256), 0, us,
@@ -1464,7 +1474,7 @@ static int trk_stream_step(gpsmi_trk* h, const void* iq, size_t n, gpsmi_trk_out
     // queued behind that kernel (no record copy, no upload-stream bookkeeping)
     const bool want_tail = in_line && (!out || out_direct);
     bool tail_used = false;
-    rc = trk_launch(h, sl, h->d_stage[s], h->d_state, h->d_state, nullptr, h->rows(), h->max_ch,
+    rc = trk_launch(h, sl, direct_in ? iq_dev : h->d_stage[s], h->d_state, h->d_state, nullptr, h->rows(), h->max_ch,
                     /*side_epilogue=*/false, want_tail ? h->in_done[s] : nullptr, &tail_used);
     sl.d_out = d_out_keep;
     h->timing = timing;
@@ -1798,6 +1808,9 @@ int gpsmi_trk_set_option(gpsmi_trk* h, const char* key, long long value) {
     } else if (!strcmp(key, "stream_inline_max")) {
         if (value < 0) return bad();
         h->stream_inline_max = (size_t)value;
+    } else if (!strcmp(key, "stream_direct_max")) {
+        if (value < 0) return bad();
+        h->stream_direct_max = (size_t)value;
     } else if (!strcmp(key, "done_by_dispatch")) {
         h->done_by_dispatch = value != 0;
     } else if (!strcmp(key, "corr_overlap")) {
@@ -1826,6 +1839,7 @@ int gpsmi_trk_get_option(gpsmi_trk* h, const char* key, long long* value) {
     else if (!strcmp(key, "corr_small2")) *value = h->corr_small2;
     else if (!strcmp(key, "span_single_max")) *value = h->span_single_max;
     else if (!strcmp(key, "stream_inline_max")) *value = (long long)h->stream_inline_max;
+    else if (!strcmp(key, "stream_direct_max")) *value = (long long)h->stream_direct_max;
     else if (!strcmp(key, "done_by_dispatch")) *value = h->done_by_dispatch;
     else if (!strcmp(key, "corr_overlap")) *value = h->corr_overlap;
     else if (!strcmp(key, "fold_chunk")) *value = h->fold_chunk;

@@ -83,6 +83,8 @@ int gpsmi_abi_sizeof(int which);
  *                       per span (80)
  *   "stream_inline_max" bytes up to which gpsmi_trk_process_stream uploads in front of the step's
  *                       own kernels (8 MiB)
+ *   "stream_direct_max" bytes up to which the kernels of a streamed step read a page-locked block
+ *                       where it lies instead of a staged copy (0: never -- measured slower)
  *   "done_by_dispatch"  1 (default): a replay's epilogue waits on the correlator dispatch's own
  *                       completion signal; 0: on an event record behind it
  *   "corr_overlap"      1: gpsmi_trk_replay_run_async queues a batch's code-phase correlation on a

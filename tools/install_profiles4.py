@@ -10,7 +10,7 @@ os.makedirs(P, exist_ok=True)
 names = {'bench_line.json': 'bench_line.json', 'bench_prof_line.json': 'bench_line_under_rocprof.json',
          'bench_kernel_stats.csv': 'bench_kernel_stats.csv', 'bench_kernel_table.md': 'bench_kernel_table.md',
          'step_timeline.txt': 'step_timeline.txt', 'step_timeline_overlapped.txt': 'step_timeline_overlapped.txt', 'bench_kernel_summary.md': 'bench_kernel_summary.md', 'pmc_counters.txt': 'pmc_counters.txt',
-         'span_prof.txt': 'span_prof.txt', 'pfa_prof.txt': 'pfa_prof.txt', 'kernel_bench.txt': 'kernel_bench.txt',
+         'span_prof.txt': 'span_prof.txt', 'span_prof_nc8.txt': 'span_prof_nc8.txt', 'pfa_prof.txt': 'pfa_prof.txt', 'kernel_bench.txt': 'kernel_bench.txt',
          'acq_bench.txt': 'acq_bench.txt', 'batched_bench.txt': 'batched_bench.txt',
          'stream_bench.txt': 'stream_bench.txt', 'cfg5_kernel_table.md': 'cfg5_kernel_table.md',
          'cfg5_line.json': 'cfg5_line.json', 'clock_settling.txt': 'clock_settling.txt',

@@ -40,6 +40,7 @@ rm -rf $out/pmc
 fi
 if [ $part = rest ] || [ $part = all ]; then
 tools/probe/span_prof 1024 > $out/span_prof.txt 2>&1 || echo "span_prof failed"
+tools/probe/span_prof_nc8 4096 1024 > $out/span_prof_nc8.txt 2>&1 || echo "span_prof_nc8 failed"    # (-DPROBE_NC=8)
 tools/probe/pfa_prof 6144 > $out/pfa_prof.txt 2>&1 || echo "pfa_prof failed"
 tools/probe/chain_floor > $out/chain_floor.txt 2>&1 || echo "chain_floor failed"
 python3 tools/kernel_bench.py > $out/kernel_bench.txt 2>&1
