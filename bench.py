@@ -477,16 +477,21 @@ def measure_dropin(E, local, raw, n_blocks):
     them on, and the recorder's raw uint16), 12 channels (MAX_SAT = 12), everything inside the
     timed loop: the host copy into page-locked memory, the upload, the kernels, the record
     read-back, the host bookkeeping and the pickling.  `tracking_only` starts the clock at the
-    first tracking block (the cold sweep's five blocks are synchronous searches)."""
+    first tracking block (the cold sweep's five blocks are synchronous searches).
+    Each format twice: `report_lag` 0 -- feed() returns a datagram on the very block the reference sends
+    it on, the GPU idles through the host's once-a-second work -- and `report_lag` 16 -- the same
+    datagrams 16 blocks later, the caller up to 16 blocks ahead of the device ("stream_depth"), which
+    works through its queue meanwhile: the mode for a recording (gpsrecv's own hand-off to saveResults /
+    UDP is asynchronous too, gpsrecv.py:496-519)."""
     import pickle
     from gpsmi.pipeline import Receiver
     from gpsmi.synth import raw_to_c64
     out = []
-    for raw_u8 in (False, True):
+    for raw_u8, lag in ((False, 0), (True, 0), (False, 16), (True, 16)):
         blocks = [np.ascontiguousarray(raw[i]) if raw_u8 else raw_to_c64(raw[i]) for i in range(n_blocks)]
         best = None
         for rep in range(2):
-            rx = Receiver(E.Config(device=local, max_sat=N_CH), raw_u8=raw_u8)
+            rx = Receiver(E.Config(device=local, max_sat=N_CH), raw_u8=raw_u8, report_lag=lag)
             n_dg, t_trk = 0, None
             E.sync(local)
             t0 = time.perf_counter()
@@ -498,11 +503,12 @@ def measure_dropin(E, local, raw, n_blocks):
                     n_dg += 1
             rx.drain()
             t1 = time.perf_counter()
+            n_dg = len(rx.result_list)
             n_ch = len(rx.act_sat_set)
             last = pickle.loads(rx.result_list[-1]) if rx.result_list else None
             rx.close()
             r = {'input': 'raw uint16 (Q<<8|I), 2 B/sample' if raw_u8 else 'complex64, 8 B/sample',
-                 'blocks': n_blocks, 'channels': n_ch, 'datagrams': n_dg,
+                 'report_lag': lag, 'blocks': n_blocks, 'channels': n_ch, 'datagrams': n_dg,
                  'us_per_block': round((t1 - t0) / n_blocks * 1e6, 2),
                  'msamples_per_s': round(n_blocks * NGPS / (t1 - t0) / 1e6, 1),
                  'x_realtime': round(n_blocks * NGPS / (t1 - t0) / 2.048e6, 1),

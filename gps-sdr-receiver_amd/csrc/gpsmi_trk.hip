@@ -1821,7 +1821,7 @@ int gpsmi_trk_set_option(gpsmi_trk* h, const char* key, long long value) {
     } else if (!strcmp(key, "stream_thread")) {
         h->stream_thread = value != 0;
     } else if (!strcmp(key, "stream_depth")) {
-        if (value != 2 && value != 3) return bad();
+        if (value < 2 || value > 64) return bad();
         h->stream_depth = (int)value;
     } else if (!strcmp(key, "correlator") || !strcmp(key, "codephase") || !strcmp(key, "debug_flags")) {
         return fail(GPSMI_E_STATE, "gpsmi_trk_set_option: '%s' is taken at create time (gpsmi_set_default)", key);

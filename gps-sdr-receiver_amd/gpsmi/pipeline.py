@@ -23,16 +23,20 @@ UDP_PORT = 61431                # gpsglob.py:82
 
 
 class Receiver:
-    def __init__(self, cfg=None, sat_all=None, raw_u8=False):
+    def __init__(self, cfg=None, sat_all=None, raw_u8=False, report_lag=0):
         """raw_u8: feed() takes the recorder's uint16 (Q << 8 | I) blocks exactly as streamData
         reads them from the file (gpsrecv.py:162-173); the decode to complex64 happens inside
-        the GPU kernels, every datagram is byte-identical to the complex64 path's."""
+        the GPU kernels, every datagram is byte-identical to the complex64 path's.
+        report_lag = L: feed() returns a datagram L blocks after the block the reference sends it
+        on (0, the default: on that block) -- the once-a-second host work then runs while the GPU
+        has L newer blocks queued instead of idling through it; the datagrams are the same."""
         self.cfg = cfg or Config()
         self.raw_u8 = bool(raw_u8)
         self.sat_all = list(SAT_ALL if sat_all is None else sat_all)
         self.acq = Acquisition(self.cfg, raw_u8=self.raw_u8)
         self.pool, self.pool_no, self.pool_worker = R.initMultiProcPool(self.cfg.max_sat,
                                                                         self.cfg, self.raw_u8)
+        self.pool.report_lag = int(report_lag)
         self.running = True
         self.smp_time = np.int64(0)                  # SMP_TIME, gpsrecv.py:29
         self.act_sat_set = set()

@@ -302,6 +302,11 @@ class GpuPool:
         self.corr_len_max = 0               # longest CORRLST among the channels of the last batch absorbed
         self.in_ring, self.out_ring, self.n_fed = None, None, 0
         self.rows = [None] * self.RING      # (a stand-in engine's records, tests)
+        # report_lag = L > 0 (satCalcLazy): the host work of a report block is done L blocks later, when
+        # the device has L newer blocks queued to work on meanwhile and (L >= the stream depth of 3) the
+        # report block's records are complete without a wait.  Same batches, same datagrams, L blocks late.
+        self.report_lag, self.depth = 0, 3
+        self.report_at, self.report_age = None, 0    # pending entries up to a report block still to absorb
 
     def acq_engine(self):
         if self.acq is None:
@@ -318,11 +323,14 @@ class GpuPool:
         if self.streamed:
             want = np.uint16 if self.raw_u8 else np.complex64
             if self.in_ring is None:
-                # four page-locked input buffers: with "stream_depth" = 3 gpsmi_trk_process_stream
-                # returns once the step three calls back is done, so the buffer of the call four back
+                # D + 1 page-locked input buffers: with "stream_depth" = D gpsmi_trk_process_stream
+                # returns once the step D calls back is done, so the buffer of the call D + 1 back
                 # is free (gpsmi.h); the host prepares block k + 1 while block k is being enqueued
-                self.trk.set_option('stream_depth', 3)
-                self.in_ring = [PinnedArray((self.cfg.ngps,), want) for _ in range(4)]
+                # (D = 3), and with a lagged report it runs up to D blocks ahead of the device, which
+                # then has work queued for the time the host spends on the report
+                self.depth = min(max(3, self.report_lag), self.RING // 2)
+                self.trk.set_option('stream_depth', self.depth)
+                self.in_ring = [PinnedArray((self.cfg.ngps,), want) for _ in range(self.depth + 1)]
                 self.out_ring = PinnedArray((self.RING, self.pool_no), OUT_DTYPE)
                 # (the addresses the library is called with, made once: ctypes conversions cost
                 # microseconds apiece)
@@ -332,7 +340,7 @@ class GpuPool:
             if data.dtype != want:          # a silent cast would turn one format into garbage of the other
                 raise TypeError(f'block dtype {data.dtype} does not match the input format '
                                 f'({np.dtype(want).name})')
-            j = self.n_fed % 4
+            j = self.n_fed % (self.depth + 1)
             buf = self.in_ring[j].array
             np.copyto(buf, data.reshape(buf.shape))
             self.trk.process_stream_ptr(self.in_ptr[j], self.out_ptr[row])
@@ -343,22 +351,47 @@ class GpuPool:
         self.pending_order = order
         self.last_stream_no = smp_time // self.cfg.ngps
 
-    # ---- everything that is pending -> host state; the batch goes to `done`
+    # ---- everything that is pending -> host state; the batch (two, if a report block is among them:
+    # the one that ends with it, then the blocks behind it) goes to `done`
     def absorb_pending(self):
-        if not self.pending:
-            return
-        k = len(self.pending)
-        smp = [t for t, _ in self.pending]
-        rows = [r for _, r in self.pending]
+        if self.report_at:
+            self._absorb(self.report_at, True)
+        self.report_at = None
+        if self.pending:
+            self._absorb(len(self.pending), True)
+
+    def report_tick(self, report):
+        """satCalcLazy, behind a block enqueued the plain way: absorb what is due."""
+        if report:
+            if self.report_lag:
+                if self.report_at:                    # (a lag of a second or more: the older one first)
+                    self._absorb(self.report_at, True)
+                self.report_at, self.report_age = len(self.pending), 0    # due `report_lag` blocks on
+            else:
+                self.absorb_pending()
+        elif self.report_at:
+            self.report_age += 1
+            if self.report_age >= self.report_lag:
+                # (lag >= the stream depth D: the library returned from the call D blocks behind the report
+                # block's when that block's step was complete -- gpsmi.h, "stream_depth" -- nothing to wait for)
+                self._absorb(self.report_at, not self.streamed or self.report_lag < self.depth)
+                self.report_at = None
+
+    def _absorb(self, k, wait):
+        pend, self.pending = self.pending[:k], self.pending[k:]
+        smp = [t for t, _ in pend]
+        rows = [r for _, r in pend]
         if self.streamed:
-            self.trk.wait()
+            if wait:
+                self.trk.wait()
             lo = rows[0]
             recs = (self.out_ring.array[lo:lo + k] if lo + k <= self.RING
                     else self.out_ring.array[rows])
         else:
             recs = np.stack([self.rows[r] for r in rows])
         order = self.pending_order
-        self.pending, self.pending_order = [], None
+        if not self.pending:
+            self.pending_order = None
         res, trig = [], []
         x = extract_records(recs, self.chan, smp, self.cfg.code_samples)   # (all worker slots: column = slot)
         cp = x.cp_array[:, [wno for _, wno in order]]
@@ -595,8 +628,7 @@ def satCalcLazy(actSatSet, pool, poolWorker, data, smpTime):
         pool.saved = {}
         pool.submit(data, smpTime, pool.pending_order or pool.steady_order)
         pool.steady_no = stream_no
-        if report:
-            pool.absorb_pending()
+        pool.report_tick(report)
         return pool.take_done()
     order = [(sno, poolWorker.index(sno)) for sno in actSatSet]
     plain = len(order) > 0 and (pool.pending_order is None or pool.pending_order == order)
@@ -616,6 +648,5 @@ def satCalcLazy(actSatSet, pool, poolWorker, data, smpTime):
     pool.steady_no, pool.steady_act, pool.steady_worker = stream_no, set(actSatSet), list(poolWorker)
     pool.steady_order = order
     pool.corr_len_max = max(len(pool.chan[w].CORRLST) for _, w in order)
-    if report:
-        pool.absorb_pending()
+    pool.report_tick(report)
     return pool.take_done()

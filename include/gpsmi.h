@@ -97,9 +97,11 @@ int gpsmi_abi_sizeof(int which);
  *                       submission thread's time waiting for the step before last / making the runtime
  *                       calls, and gpsmi_trk_wait's time waiting for that thread / for the device
  *   "stream_depth"      2 (default): gpsmi_trk_process_stream returns once the step of the call
- *                       BEFORE LAST is complete (three caller buffers in rotation); 3: the step three
- *                       calls back (four buffers) -- with the submission thread the caller then hands
- *                       over block k + 1 while block k is still being enqueued              */
+ *                       BEFORE LAST is complete (three caller buffers in rotation); D = 3 .. 64: the
+ *                       step D calls back (D + 1 buffers) -- with the submission thread the caller
+ *                       then hands over block k + 1 while block k is still being enqueued, and may
+ *                       run up to D blocks ahead of the device (the jobs wait in the thread's queue;
+ *                       the device still holds two steps at a time)                        */
 int gpsmi_set_default(const char* key, long long value);
 int gpsmi_clear_default(const char* key);
 int gpsmi_device_count(int* n);

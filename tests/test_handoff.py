@@ -115,3 +115,26 @@ def test_receiver_feed_equals_the_reference_process(raw_u8):
     rx.close()
     assert at == [32 * (k + 1) - 1 for k in range(len(ref_dgs))]
     compare(got, ref_dgs, exact=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('lag', [3, 16])
+def test_a_lagged_report_sends_the_same_datagrams_later(lag):
+    """Receiver(report_lag=L): the once-a-second host work is done L blocks behind the report block,
+    while the GPU works on the blocks queued meanwhile (L = 16: the caller runs up to 16 blocks ahead
+    of the device, "stream_depth"); same batches, same datagrams."""
+    from gpsmi.pipeline import Receiver
+    ref_dgs, n_blocks, _ = handoff_fixture()
+    raw = handoff_raw_blocks()
+    rx = Receiver(raw_u8=True, report_lag=lag)
+    at = []
+    for i, r in enumerate(raw):
+        if rx.feed(r) is not None:
+            at.append(i)
+    rx.drain()
+    got = [pickle.loads(d) for d in rx.result_list]
+    rx.close()
+    steady = [i for i in at if i % 32 != 31]               # (a report inside the channels' sweeps is not lagged)
+    assert steady and all(i % 32 == (31 + lag) % 32 for i in steady)
+    assert len(got) == len(ref_dgs)
+    compare(got, ref_dgs, exact=False)

@@ -147,3 +147,44 @@ def test_messages_and_answers_have_the_reference_shapes(golden_default):
         q.put(('done', None))
     th.join(timeout=5)
     assert not th.is_alive()
+
+
+def test_a_lagged_report_gives_the_same_batches_later(golden_default):
+    """satCalcLazy with GpuPool.report_lag = L: the batch that ends with a report block is absorbed L
+    blocks later (pipeline.Receiver(report_lag=L)); its content -- result list, code phases, frames --
+    and everything after it is what the unlagged run gives."""
+    g = golden_default
+    cfg = Config()
+    init = g['trk_init']
+    found = [(20.0 - c, int(init[c, 0]), float(init[c, 1]), int(init[c, 2])) for c in range(len(init))]
+    data = np.zeros(cfg.ngps, np.complex64)
+    nb, first = 44, 20                       # stream numbers 21 .. 64: report blocks 32 and 64
+
+    def run(lag):
+        pool = R.GpuPool(11, cfg, trk=FixtureEngine(g, 11))
+        pool.report_lag = lag
+        worker, act = R.initPoolStreams(pool, 11, [0] * 11, set(), {e[1] for e in found[:8]}, found)
+        out = []
+        for i in range(nb):
+            smp = np.int64((first + i + 1) * cfg.ngps)
+            out += [(i, b) for b in R.satCalcLazy(act, pool, worker, data, smp)]
+        pool.absorb_pending()
+        out += [(nb, b) for b in pool.take_done()]
+        return out
+
+    plain, lagged = run(0), run(5)
+    with_frames = lambda runs: [(i, b) for i, b in runs if any(r[2] for r in b.res)]
+    fa, fb = with_frames(plain), with_frames(lagged)
+    assert len(fa) == len(fb) >= 1
+    assert [i for i, _ in fb][0] == [i for i, _ in fa][0] + 5          # the first report: five blocks later
+    for (_, a), (_, b) in zip(fa, fb):
+        assert a.sats == b.sats and list(a.smp_times) == list(b.smp_times)
+        np.testing.assert_array_equal(a.code_phase, b.code_phase)
+        assert len(a.res) == len(b.res)
+        for (sw_a, s_a, f_a, cp_a, q_a), (sw_b, s_b, f_b, cp_b, q_b) in zip(a.res, b.res):
+            assert (sw_a, s_a, cp_a) == (sw_b, s_b, cp_b)
+            assert tuple(map(float, q_a)) == tuple(map(float, q_b))
+            assert [sorted(d.items(), key=str) for d in f_a] == [sorted(d.items(), key=str) for d in f_b]
+    # block for block the same code phases overall
+    cat = lambda runs: np.concatenate([b.code_phase for _, b in runs])
+    np.testing.assert_array_equal(cat(plain), cat(lagged))

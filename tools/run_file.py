@@ -58,27 +58,32 @@ def cpu_cold_acquisition(path, n_blocks=5):
             'found': [(int(s), float(f), int(d)) for _, s, f, d in found]}
 
 
-def run(path, seconds=None, start_stream=0, save_pickle=None, ephemerides=None, cpu_acq=False):
+def run(path, seconds=None, start_stream=0, save_pickle=None, ephemerides=None, cpu_acq=False, report_lag=16):
     from gpsmi import ingest, position as P
     from gpsmi.engine import Config
     from gpsmi.pipeline import Receiver, save_results
     cfg = Config()
-    rx = Receiver(cfg, raw_u8=True)
+    # (a recording: the datagrams may come out `report_lag` blocks behind the block they belong to, the
+    # reader then runs ahead of the GPU instead of stalling it once a second -- pipeline.Receiver)
+    rx = Receiver(cfg, raw_u8=True, report_lag=report_lag)
     solver = P.PositionSolver(cfg.code_samples, cfg.n_cyc, ephemerides=ephemerides)
     max_blocks = None if seconds is None else int(seconds * 1000 // cfg.n_cyc)
     fixes, n_dg, n_blocks, found = [], 0, 0, None
     t0 = time.perf_counter()
     for raw in ingest.read_raw_blocks(path, cfg.ngps, start_stream):
-        dg = rx.feed(raw)
+        rx.feed(raw)
         n_blocks += 1
         if found is None and not rx.sweep_all_freq:
             found = list(rx.found_sats)
-        if dg is not None:
+        for dg in rx.result_list[n_dg:]:           # (every datagram, in order: RESULT_LIST)
             n_dg += 1
             fixes += solver.feed(pickle.loads(dg))
         if max_blocks is not None and n_blocks >= max_blocks:
             break
     rx.drain()
+    for dg in rx.result_list[n_dg:]:
+        n_dg += 1
+        fixes += solver.feed(pickle.loads(dg))
     wall = time.perf_counter() - t0
     if save_pickle:
         save_results(save_pickle, rx.result_list)
@@ -111,13 +116,15 @@ def main():
     ap.add_argument('--save-pickle', default=None, help='write the datagram list as SAVE_PICKLE does')
     ap.add_argument('--ephemeris', default=None, help='a saved EPHEM_FILE (gpsEphem.json) to start from')
     ap.add_argument('--cpu-acq', action='store_true', help='time the CPU cold acquisition (configs[0]) too')
+    ap.add_argument('--report-lag', type=int, default=16,
+                    help='blocks a datagram may trail the block it belongs to (0: none, as a live receiver)')
     ap.add_argument('--json', action='store_true', help='one JSON line instead of text')
     a = ap.parse_args()
     eph = None
     if a.ephemeris:
         with open(a.ephemeris) as f:
             eph = {int(k): v for k, v in json.load(f).items()}
-    out = run(a.recording, a.seconds, a.start_stream, a.save_pickle, eph, a.cpu_acq)
+    out = run(a.recording, a.seconds, a.start_stream, a.save_pickle, eph, a.cpu_acq, a.report_lag)
     if a.json:
         print(json.dumps(out))
         return
