@@ -138,3 +138,27 @@ def test_a_lagged_report_sends_the_same_datagrams_later(lag):
     assert steady and all(i % 32 == (31 + lag) % 32 for i in steady)
     assert len(got) == len(ref_dgs)
     compare(got, ref_dgs, exact=False)
+
+
+@pytest.mark.gpu
+def test_a_command_flushes_a_lagged_report():
+    """A SWEEP command (or anything else that needs the host state) while a report is still outstanding:
+    the pool absorbs the report's batch first, then the blocks behind it; the datagrams are those of the
+    unlagged receiver given the same command at the same block."""
+    from gpsmi.pipeline import Receiver
+    raw = handoff_raw_blocks()[:80]
+
+    def run(lag):
+        rx = Receiver(raw_u8=True, report_lag=lag)
+        for i, r in enumerate(raw):
+            rx.feed(r)
+            if i == 36:                                    # five blocks behind the report block 31
+                rx.command(b'SWEEP')
+        rx.drain()
+        out = list(rx.result_list)                         # (the pickled datagrams themselves)
+        rx.close()
+        return out
+
+    a, b = run(0), run(16)
+    assert len(a) == len(b) >= 2
+    assert a == b
