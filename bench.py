@@ -848,15 +848,24 @@ def main():
             dist.all_gather(parts, mine)
             gathered[:] = np.concatenate([p.numpy().view(E.PEAK_DTYPE) for p in parts])
 
+    host_ns = {'wait': 0, 'all': 0}                  # host time inside the two blocking waits / inside step()
+
     def finish_search():
         """wait for the search enqueued one step ago; gather its peak records"""
+        tw = time.perf_counter_ns()
         acq.engine.wait()
+        host_ns['wait'] += time.perf_counter_ns() - tw
         if recording[0]:
             acq_ms.append(acq.engine.last_ms())
         if world > 1:
             gather_peaks()
 
     def step(k, record):
+        ts = time.perf_counter_ns()
+        step_body(k, record)
+        host_ns['all'] += time.perf_counter_ns() - ts
+
+    def step_body(k, record):
         # Software pipeline of depth two: the host enqueues step k (search on its own
         # handle and stream, tracking batch, read-back on the copy stream) and only
         # then waits for step k-1, so that neither the read-back nor the host's launch
@@ -878,7 +887,9 @@ def main():
         acq.engine.search_async(d_iq0.ptr, acq_n, shard, acq_freqs, acq_navg, acq_pin.array,
                                 d_send.ptr if world > 1 else None)
         trk.replay_fetch_async(pins[k & 1].array)
+        tw = time.perf_counter_ns()
         trk.wait_prev()
+        host_ns['wait'] += time.perf_counter_ns() - tw
         if record and k > 0:
             record_last(cold=record, full=(k - 1) % TIMED_EVERY == 0)
 
@@ -914,9 +925,11 @@ def main():
     trk.wait()
     barrier()
     recording[0] = True
+    host_ns['wait'] = host_ns['all'] = 0
     t0 = time.perf_counter()
     for k in range(a.steps):
         step(k, 'overlapped' if overlap else True)
+    host_timed = dict(host_ns)
     finish_search()                         # the last step: its search, ...
     trk.wait()                              # ... its kernels and its copy
     barrier()
@@ -1058,6 +1071,10 @@ def main():
                                            'correlator': round(float(np.mean(ovl['corr'])), 4),
                                            'codephase_correlation': round(float(np.mean(ovl['cp'])), 4)}
                                           if ovl['corr'] else None),
+                # where the host thread spent the timed region: inside its two blocking waits (the
+                # device is the bound) or enqueuing (the host is)
+                'host_us_per_step': round(host_timed['all'] / a.steps / 1e3, 1),
+                'host_wait_us_per_step': round(host_timed['wait'] / a.steps / 1e3, 1),
             },
             'roofline': {
                 'bound': 'hbm', 'kernel': 'trk_span_kernel',

@@ -43,6 +43,7 @@ static OptDef g_opts[] = {
     {"stream_thread", "GPSMI_STREAM_THREAD", false, 0},
     {"stream_depth", "GPSMI_STREAM_DEPTH", false, 0},
     {"fold_chunk", "GPSMI_FOLD_CHUNK", false, 0},
+    {"epilogue_form", "GPSMI_EPILOGUE_FORM", false, 0},
     {"debug_flags", "GPSMI_DEBUG_FLAGS", false, 0},
 };
 static std::mutex g_opts_mutex;

@@ -354,14 +354,14 @@ __device__ __forceinline__ void epilogue_job(const gpsmi_trk_state& si, gpsmi_tr
 // byte of an open channel's record is written by the correlation kernel and epilogue_job, so
 // the result buffer needs no memset per launch
 __device__ __forceinline__ void epilogue_closed(const gpsmi_trk_state& si, gpsmi_trk_state& so,
-                                                gpsmi_trk_out& out, bool copy, int lane) {
+                                                gpsmi_trk_out& out, bool copy, int lane, int nlanes = 64) {
     if (copy) {
         const int* a = reinterpret_cast<const int*>(&si);
         int* b = reinterpret_cast<int*>(&so);
-        for (int i = lane; i < (int)(sizeof(gpsmi_trk_state) / 4); i += 64) b[i] = a[i];
+        for (int i = lane; i < (int)(sizeof(gpsmi_trk_state) / 4); i += nlanes) b[i] = a[i];
     }
     int* z = reinterpret_cast<int*>(&out);
-    for (int i = lane; i < (int)(sizeof(gpsmi_trk_out) / 4); i += 64) z[i] = 0;
+    for (int i = lane; i < (int)(sizeof(gpsmi_trk_out) / 4); i += nlanes) z[i] = 0;
 }
 
 // One wave per job (four jobs per workgroup): the batch form.
@@ -379,6 +379,294 @@ __global__ __launch_bounds__(256) void trk_epilogue_kernel(
     }
     epilogue_job(st_in[job], st_out[job], mid[job].delay_used, partial + (size_t)job * (P.n_cyc + 1), P,
                  out[job], lane, s_mag[wave], s_dev[wave], s_real[wave], s_df[wave]);
+}
+
+// ---- The batch form with EIGHT LANES per job (round 4; option "epilogue_form" = 1, the default).
+// The wave-per-job kernel above spends a whole wave -- and, beside the code-phase correlation of the
+// next batch, a wave slot with its registers on every SIMD of a CU for the ~10 us of its dependent
+// chain -- on 33 dumps: 12288 jobs = 3072 workgroups that each keep one of that kernel's workgroups
+// off a CU while they wait for their own loads.  Here lane j of a job's eight carries the dumps
+// i = j, j + 8, j + 16, ... (slot k = i / 8; the (N_CYC + 1)-th dump is slot N_CYC / 8 of lane 0), a
+// wave is a workgroup and takes eight jobs: 1536 one-wave workgroups instead of 3072 four-wave ones,
+// an eighth of the wave slots.  The arithmetic is epilogue_job's, operation by operation:
+//   * numpy's pairwise sum IS this layout: its eight strided accumulators r[j] = a[j] + a[j + 8] + ...
+//     are the lanes' own slots added in slot order, the tree is the same three DPP steps (they stay
+//     inside a group of eight lanes), the tail element comes from lane 0's last slot;
+//   * the masks of the edge scan (dump positive / negative / step large) and the +-1 jumps of the phase
+//     unwrapping are bits i of per-job 64-bit words, OR-ed over the eight lanes by DPP; the scan is the
+//     same arithmetic on them in every lane of the group, the unwrap count of dump i is two popcounts
+//     (small integers: exact, like the float prefix sum of the wave form);
+//   * the neighbour dump (i - 1) is lane j - 1's slot k, or lane 7's slot k - 1 for j = 0: one
+//     rotation inside the group per slot.
+// Same bits as the wave form (tests/test_gpu_trk.py: both forms against each other and replay ==
+// closed loop, whose single-block epilogue is the wave form).
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_or(unsigned v) {
+    return v | (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+// OR over the eight lanes of a group, in every lane of it
+__device__ __forceinline__ unsigned long long or8(unsigned long long m) {
+    unsigned lo = (unsigned)m, hi = (unsigned)(m >> 32);
+    lo = dpp_or<0xB1>(lo); hi = dpp_or<0xB1>(hi);       // quad_perm [1,0,3,2]
+    lo = dpp_or<0x4E>(lo); hi = dpp_or<0x4E>(hi);       // quad_perm [2,3,0,1]
+    lo = dpp_or<0x141>(lo); hi = dpp_or<0x141>(hi);     // row_half_mirror
+    return ((unsigned long long)hi << 32) | lo;
+}
+// lane `l` of this lane's group of eight
+__device__ __forceinline__ float grp_get(float v, int lane, int l) { return __shfl(v, (lane & ~7) | l, 64); }
+// np.sum of a[0 .. n), element i in slot i / 8 of lane i % 8; n = 8 (K - 1) or 8 (K - 1) + 1
+template <int K>
+__device__ __forceinline__ float np_sum8(const float (&a)[K], int n, int lane) {
+    float r = a[0];
+#pragma unroll
+    for (int k = 1; k < K - 1; ++k) r = add_rn(r, a[k]);
+    r = dpp_add0<0xB1, 0xF>(r);
+    r = dpp_add0<0x4E, 0xF>(r);
+    r = dpp_add0<0x141, 0xF>(r);
+    const float t = grp_get(a[K - 1], lane, 0);
+    if (n > 8 * (K - 1)) r = add_rn(r, t);
+    return r;
+}
+// np_sum_f32_wave for a group of eight lanes (a: LDS, any n <= 128), every lane of the group returning it
+__device__ __forceinline__ float np_sum_f32_grp(const float* a, int n, int j) {
+    if (n < 8) return np_sum_f32(a, n);
+    const int body = n - (n % 8);
+    float r = a[j];
+    for (int i = 8; i < body; i += 8) r = add_rn(r, a[i + j]);
+    r = dpp_add0<0xB1, 0xF>(r);
+    r = dpp_add0<0x4E, 0xF>(r);
+    r = dpp_add0<0x141, 0xF>(r);
+    for (int i = body; i < n; ++i) r = add_rn(r, a[i]);
+    return r;
+}
+
+template <int NCV>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void trk_epilogue8_kernel(
+    const gpsmi_trk_state* __restrict__ st_in, gpsmi_trk_state* __restrict__ st_out,
+    const JobMid* __restrict__ mid, const float2* __restrict__ partial, TrkParams P,
+    int njobs, gpsmi_trk_out* __restrict__ out) {
+    constexpr int nc = NCV, K = NCV / 8 + 1, KD = (GPSMI_MAX_DUMPS + 7) / 8;
+    static_assert(NCV % 8 == 0 && NCV + 1 <= GPSMI_MAX_DUMPS, "slots of eight dumps");
+    __shared__ float s_real[8][NCV + 8], s_df[8][GPSMI_MAX_DF];
+    const int lane = threadIdx.x & 63, j = lane & 7, jw = lane >> 3;
+    const int job = blockIdx.x * 8 + jw;
+    if (job >= njobs) return;                       // (whole groups: nothing below leaves a group)
+    const gpsmi_trk_state& si = st_in[job];
+    gpsmi_trk_state& so = st_out[job];
+    gpsmi_trk_out& o = out[job];
+    const JobMid md = mid[job];
+    if (!md.active) {
+        epilogue_closed(si, so, o, st_out != st_in, j, 8);
+        return;
+    }
+    const float2* S = partial + (size_t)job * (nc + 1);
+    const int d = md.delay_used, cs = P.cs;
+    float* s_real_w = s_real[jw];
+    float* s_df_w = s_df[jw];
+    const int nps = si.nps, df_len = si.df_len, was_locked = si.phase_locked;
+    const float freq0 = si.freq, phase0 = si.phase, omega0 = si.omega0;
+    const float prev_r = si.prev_sum_re, prev_i = si.prev_sum_im;
+    const int edge_state0 = si.edge_state;
+    const float prev_signal0 = si.prev_signal, std_dev0 = si.std_dev;
+    for (int i = j; i < df_len; i += 8) s_df_w[i] = si.df[i];
+
+    // ---- prompt dumps (epilogue_job: gpslib.py:1403-1420, :1440)
+    const int n1 = nps + d;
+    int nd;
+    float gr[K], gi[K], car_r = 0.f, car_i = 0.f;
+    int nps_new = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) gr[k] = gi[k] = 0.f;
+    if (n1 == 0) {
+        nd = nc;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int i = j + 8 * k;
+            if (i < nd) { gr[k] = S[i + 1].x / (float)cs; gi[k] = S[i + 1].y / (float)cs; }
+        }
+    } else {
+        nd = (d == 0) ? nc + 1 : nc;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int i = j + 8 * k;
+            if (i == 0) {
+                gr[k] = (prev_r + S[0].x) / (float)n1;
+                gi[k] = (prev_i + S[0].y) / (float)n1;
+            } else if (i < nd) {
+                gr[k] = S[i].x / (float)cs;
+                gi[k] = S[i].y / (float)cs;
+            }
+        }
+        if (d != 0) { car_r = S[nc].x; car_i = S[nc].y; nps_new = cs - d; }
+    }
+#pragma unroll
+    for (int k = 0; k < KD; ++k) {
+        const int i = j + 8 * k;
+        if (i < GPSMI_MAX_DUMPS) {
+            o.dumps[2 * i] = (k < K && i < nd) ? gr[k < K ? k : 0] : 0.f;
+            o.dumps[2 * i + 1] = (k < K && i < nd) ? gi[k < K ? k : 0] : 0.f;
+        }
+    }
+    // the dump before dump i: slot k of lane j - 1, for j = 0 slot k - 1 of lane 7
+    const int rot = (lane & ~7) | ((j + 7) & 7);
+
+    // ---- edge scan (epilogue_job: gpslib.py:1394-1398, :1421-1436)
+    unsigned long long edge_mask = 0;
+    int edge_sign0 = 0, edge_state = edge_state0, ms_count = 0;
+    float prev_signal = prev_signal0;
+    if (was_locked) {
+        const unsigned long long V = (1ull << nd) - 1;
+        const float thr = mul_rn(3.0f, std_dev0);
+        unsigned long long Pm = 0, Nm = 0, Bm = 0;
+        float before = prev_signal0;                   // lane 0: slot k - 1 of lane 7
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int i = j + 8 * k;
+            const float up = __shfl(gr[k], rot, 64);
+            const float re_prev = j == 0 ? before : up;
+            before = up;
+            if (i < nd) {
+                if (gr[k] > 0.f) Pm |= 1ull << i;
+                if (gr[k] < 0.f) Nm |= 1ull << i;
+                if (fabsf(sub_rn(gr[k], re_prev)) > thr) Bm |= 1ull << i;
+            }
+        }
+        Pm = or8(Pm); Nm = or8(Nm); Bm = or8(Bm);
+        const unsigned long long Pp = (Pm << 1) | (prev_signal0 > 0.f ? 1ull : 0ull);
+        const unsigned long long Np = (Nm << 1) | (prev_signal0 < 0.f ? 1ull : 0ull);
+        unsigned long long todo = V;
+        int p = edge_state0 == 2 ? 0 : edge_state0;
+        if (edge_state0 == 0) {
+            const unsigned long long nz = Pm | Nm;
+            if (nz == 0) {
+                todo = 0;
+            } else {
+                const int q = __builtin_ctzll(nz);
+                p = ((Pm >> q) & 1) ? 1 : -1;
+                edge_sign0 = p;
+                todo = V & ~((2ull << q) - 1);
+            }
+        }
+        while (p != 0 && todo != 0) {
+            const unsigned long long cand = (p > 0 ? (Pp & ~Pm) : (Np & ~Nm)) & Bm & todo;
+            if (cand == 0) break;
+            const int i = __builtin_ctzll(cand);
+            edge_mask |= 1ull << i;
+            p = ((Pm >> i) & 1) ? 1 : (((Nm >> i) & 1) ? -1 : 0);
+            todo &= ~((2ull << i) - 1);
+        }
+        if (edge_state0 != 0 || edge_sign0 != 0) edge_state = p == 0 ? 2 : p;
+        const float last_full = grp_get(gr[K - 2], lane, 7), last_extra = grp_get(gr[K - 1], lane, 0);
+        prev_signal = nd == nc + 1 ? last_extra : last_full;       // the real part of dump nd - 1
+        ms_count = nd;
+    }
+
+    // ---- amplitude statistics (epilogue_job: gpslib.py:1186-1187)
+    float mag[K], dev[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) mag[k] = hypotf(gr[k], gi[k]);
+    const float mmean = np_sum8<K>(mag, nd, lane) / (float)nd;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float e = sub_rn(mag[k], mmean);
+        dev[k] = mul_rn(e, e);
+    }
+    const float sdev = sqrtf(np_sum8<K>(dev, nd, lane) / (float)nd);
+
+    // ---- phaseLockedLoop (epilogue_job: gpslib.py:1215-1262)
+    float ph[K], real[K];
+    unsigned long long Jp = 0, Jn = 0;                 // dumps whose unwrap step is +1 / -1
+    {
+        float before = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int i = j + 8 * k;
+            ph[k] = atanf(gi[k] / gr[k]);
+            const float up = __shfl(ph[k], rot, 64);
+            const float ph_prev = j == 0 ? before : up;
+            before = up;
+            if (i >= 1 && i < nd) {
+                const float delta = sub_rn(ph[k], ph_prev);
+                if (fabsf(delta) > 2.0f) {
+                    if (delta > 0.f) Jn |= 1ull << i;
+                    else Jp |= 1ull << i;
+                }
+            }
+        }
+    }
+    Jp = or8(Jp); Jn = or8(Jn);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int i = j + 8 * k;
+        const unsigned long long upto = (2ull << i) - 1;               // dumps 0 .. i
+        const float jump = (float)(__builtin_popcountll(Jp & upto) - __builtin_popcountll(Jn & upto));
+        real[k] = (i == 0) ? ph[k] : add_rn(ph[k], mul_rn(jump, kPiF));
+        if (i < nd) s_real_w[i] = real[k];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const float offset = np_sum_f32(s_real_w + (nd - 4), 4) / 4.0f;
+    const float pdev = np_sum8<K>(real, nd, lane) / (float)nd;
+    const float max_df = 20.0f / (float)P.df_no;
+    int locked = was_locked;
+    int new_len;
+    float df;
+    if (locked) {
+        const float mean_df = np_sum_f32_grp(s_df_w, df_len, j) / (float)df_len;
+        df = add_rn(pdev, mean_df);
+        if (fabsf(df) > max_df) df = (df > 0.f ? 1.f : -1.f) * max_df;
+        const int shift = df_len >= P.df_no ? 1 : 0;
+        new_len = df_len - shift + 1;
+        for (int i = j; i < new_len - 1; i += 8) so.df[i] = s_df_w[i + shift];
+        if (j == 0) so.df[new_len - 1] = df;
+    } else {
+        df = mul_rn(10.0f, pdev);
+        new_len = 1;
+        if (j == 0) so.df[0] = df;
+    }
+    if (fabsf(pdev) < 0.1f) locked = 1;
+
+    // ---- state update (epilogue_job: gpslib.py:1178 via :1345-1346, then :1205-1208)
+    const float om = omega0 != 0.f ? omega0 : omega_of(freq0);
+    float phase = add_rn(phase0, mul_rn(om, P.t_last));
+    float mod = fmodf(phase, kTwoPiF);
+    if (mod != 0.f && mod < 0.f) mod = add_rn(mod, kTwoPiF);
+    phase = add_rn(mod, offset);
+    float freq = add_rn(freq0, df);
+    float om_new = 0.f;
+    if (freq > P.max_freq) { freq = P.max_freq; om_new = P.om_max; }
+    else if (freq < P.min_freq) { freq = P.min_freq; om_new = P.om_min; }
+
+    if (j == 0) {
+        so.prn = si.prn;
+        so.delay = d;
+        so.freq = freq;
+        so.phase = phase;
+        so.phase_locked = locked;
+        so.nps = nps_new;
+        so.prev_sum_re = car_r;
+        so.prev_sum_im = car_i;
+        so.df_len = new_len;
+        so.omega0 = om_new;
+        so.edge_state = edge_state;
+        so.prev_signal = prev_signal;
+        so.std_dev = sdev;
+        so.reserved = 0;
+        o.n_dumps = nd;
+        o.first_len = (n1 == 0) ? cs : n1;
+        o.std_dev = sdev;
+        o.amplitude = mmean / sdev;
+        o.df = df;
+        o.phase_shift = offset;
+        o.freq = freq;
+        o.phase = phase;
+        o.phase_locked = locked;
+        o.nps = nps_new;
+        o.edge_mask = (uint32_t)edge_mask;
+        o.edge_mask_hi = (uint32_t)(edge_mask >> 32);
+        o.edge_sign0 = edge_sign0;
+        o.ms_count = ms_count;
+        o.reserved1 = 0;
+    }
 }
 
 // One workgroup per job: behind the single-block form of the span correlator (the closed
@@ -546,6 +834,8 @@ struct gpsmi_trk {
     int codephase = 0;               // option "codephase" as taken at create time
     int corr_overlap = 0;            // option "corr_overlap": see gpsmi_trk_replay_run_async
     int fold_chunk = 0;              // option "fold_chunk": blocks per fold -> correlation piece at CS = 16368
+    int epilogue_form = 1;           // option "epilogue_form": 1 = eight lanes per job in the batch epilogue
+                                     // (trk_epilogue8_kernel), 0 = a wave per job (trk_epilogue_kernel); same bits
     float* d_code_eo = nullptr;      // [GPSMI_MAX_PRN + 1][...]: the replica re-cut for the matrix correlators.  Span form
                                      // (2048): four planes by index mod 4, entry h of plane e = replica[(4 h + e) mod 2048],
                                      // 1024 entries each (a lane's run never wraps); span8 form: two planes by index
@@ -837,13 +1127,32 @@ static int trk_launch(gpsmi_trk* h, gpsmi_trk::Slot& sl, const void* d_iq_v,
         GPSMI_LAUNCH_EPI_SPAN(16);
     else if (span_single)
         GPSMI_LAUNCH_EPI_SPAN(8);
-    else if (tail_stop) {
-        hipExtLaunchKernelGGL(trk_epilogue_kernel, dim3((njobs + 3) / 4), dim3(256), 0, es, nullptr, tail_stop,
-                              0, c_in, st_out, c_mid, c_partial, P, njobs, sl.d_out);
-        stop_used = true;
-    } else
-        hipLaunchKernelGGL(trk_epilogue_kernel, dim3((njobs + 3) / 4), dim3(256), 0, es, st_in,
-                           st_out, sl.d_mid, sl.d_partial, P, njobs, sl.d_out);
+    else if (h->epilogue_form == 0) {        // a wave per job
+        if (tail_stop) {
+            hipExtLaunchKernelGGL(trk_epilogue_kernel, dim3((njobs + 3) / 4), dim3(256), 0, es, nullptr,
+                                  tail_stop, 0, c_in, st_out, c_mid, c_partial, P, njobs, sl.d_out);
+            stop_used = true;
+        } else
+            hipLaunchKernelGGL(trk_epilogue_kernel, dim3((njobs + 3) / 4), dim3(256), 0, es, st_in,
+                               st_out, sl.d_mid, sl.d_partial, P, njobs, sl.d_out);
+    } else {                                 // eight lanes per job (the default)
+#define GPSMI_LAUNCH_EPI8(NCV)                                                                           \
+    do {                                                                                                \
+        if (tail_stop) {                                                                                \
+            hipExtLaunchKernelGGL(trk_epilogue8_kernel<NCV>, dim3((njobs + 7) / 8), dim3(64), 0, es,    \
+                                  nullptr, tail_stop, 0, c_in, st_out, c_mid, c_partial, P, njobs,      \
+                                  sl.d_out);                                                            \
+            stop_used = true;                                                                           \
+        } else {                                                                                        \
+            hipLaunchKernelGGL(trk_epilogue8_kernel<NCV>, dim3((njobs + 7) / 8), dim3(64), 0, es, c_in, \
+                               st_out, c_mid, c_partial, P, njobs, sl.d_out);                           \
+        }                                                                                               \
+    } while (0)
+        if (P.n_cyc == 32) GPSMI_LAUNCH_EPI8(32);
+        else if (P.n_cyc == 16) GPSMI_LAUNCH_EPI8(16);
+        else GPSMI_LAUNCH_EPI8(8);
+#undef GPSMI_LAUNCH_EPI8
+    }
 #undef GPSMI_LAUNCH_EPI_SPAN
     if (tail_stop_used) *tail_stop_used = stop_used;
     GPSMI_HIP(hipGetLastError());
@@ -1155,7 +1464,8 @@ static int trk_build(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk* h) {
         {"corr_cg", h->corr_cg}, {"span_single_max", h->span_single_max}, {"stream_inline_max", (long long)h->stream_inline_max},
         {"stream_direct_max", (long long)h->stream_direct_max},
         {"done_by_dispatch", h->done_by_dispatch}, {"corr_overlap", h->corr_overlap},
-        {"stream_thread", h->stream_thread}, {"stream_depth", h->stream_depth}, {"fold_chunk", h->fold_chunk}};
+        {"stream_thread", h->stream_thread}, {"stream_depth", h->stream_depth}, {"fold_chunk", h->fold_chunk},
+        {"epilogue_form", h->epilogue_form}};
     for (const auto& t : tun) {
         default_opt(t.key, &v, t.fallback);
         if (v != t.fallback) (void)gpsmi_trk_set_option(h, t.key, v);   // (an out-of-range default is ignored)
@@ -1818,6 +2128,9 @@ int gpsmi_trk_set_option(gpsmi_trk* h, const char* key, long long value) {
     } else if (!strcmp(key, "fold_chunk")) {
         if (value < 0 || value > (1 << 20)) return bad();
         h->fold_chunk = (int)value;
+    } else if (!strcmp(key, "epilogue_form")) {
+        if (value != 0 && value != 1) return bad();
+        h->epilogue_form = (int)value;
     } else if (!strcmp(key, "stream_thread")) {
         h->stream_thread = value != 0;
     } else if (!strcmp(key, "stream_depth")) {
@@ -1843,6 +2156,7 @@ int gpsmi_trk_get_option(gpsmi_trk* h, const char* key, long long* value) {
     else if (!strcmp(key, "done_by_dispatch")) *value = h->done_by_dispatch;
     else if (!strcmp(key, "corr_overlap")) *value = h->corr_overlap;
     else if (!strcmp(key, "fold_chunk")) *value = h->fold_chunk;
+    else if (!strcmp(key, "epilogue_form")) *value = h->epilogue_form;
     else if (!strcmp(key, "stream_thread")) *value = h->stream_thread;
     else if (!strcmp(key, "stream_depth")) *value = h->stream_depth;
     else if (!strcmp(key, "stat_stream_steps")) *value = h->stat_steps;

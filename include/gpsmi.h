@@ -87,6 +87,9 @@ int gpsmi_abi_sizeof(int which);
  *                       where it lies instead of a staged copy (0: never -- measured slower)
  *   "done_by_dispatch"  1 (default): a replay's epilogue waits on the correlator dispatch's own
  *                       completion signal; 0: on an event record behind it
+ *   "epilogue_form"     1 (default): the batch epilogue takes eight lanes per (block, channel) job
+ *                       (1536 one-wave workgroups per 1024-block batch); 0: a wave per job (3072
+ *                       four-wave workgroups).  Same bits; DESIGN.md 4.5
  *   "corr_overlap"      1: gpsmi_trk_replay_run_async queues a batch's code-phase correlation on a
  *                       second stream, so that it runs beside the previous batch's correlator
  *                       (throughput mode; 0, the default, keeps every kernel alone on the chip)

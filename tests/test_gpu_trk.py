@@ -141,6 +141,36 @@ def test_replay_reproduces_closed_loop(closed_loop):
             assert np.array_equal(nxt[i, c]['df'][:n], states[i + 1, c]['df'][:n])
 
 
+@pytest.mark.parametrize('form', [1, 0])
+def test_batch_epilogue_forms_reproduce_closed_loop(closed_loop, form):
+    """The batch form of the correlator with each form of the batch epilogue (option
+    "epilogue_form": 1 = eight lanes per job, trk_epilogue8_kernel; 0 = a wave per job) against
+    the closed loop, whose single-block epilogue is the wave form: outputs bytewise, states field
+    by field (the edge-scan words included)."""
+    from gpsmi.engine import TrkEngine, DeviceBuffer
+    _, outs, states, blocks = closed_loop
+    nb, nch = outs.shape
+    buf = DeviceBuffer(nb * blocks[0].nbytes)
+    for i, b in enumerate(blocks):
+        buf.upload(b, i * b.nbytes)
+    eng = TrkEngine(max_ch=nch)
+    eng.set_option('span_single_max', 1)             # the batch kernels whatever the launch size
+    eng.set_option('epilogue_form', form)
+    assert eng.get_option('epilogue_form') == form
+    rep = eng.replay(buf.ptr, nb, states, outs['delay_used'])
+    nxt = eng.replay_states(nb)
+    buf.free()
+    eng.close()
+    assert rep.tobytes() == outs.tobytes()
+    for k in ('prn', 'delay', 'freq', 'phase', 'phase_locked', 'nps', 'prev_sum_re', 'prev_sum_im',
+              'df_len', 'omega0', 'edge_state', 'prev_signal', 'std_dev'):
+        assert nxt[:-1][k].tobytes() == states[1:][k].tobytes(), k
+    for i in range(nb - 1):
+        for c in range(nch):
+            n = int(states[i + 1, c]['df_len'])
+            assert nxt[i, c]['df'][:n].tobytes() == states[i + 1, c]['df'][:n].tobytes()
+
+
 def test_replay_without_forced_delay(closed_loop):
     """With no recorded DELAY given, replay derives it from each block's own
     correlation, exactly as the closed loop does."""
