@@ -953,6 +953,14 @@ def main():
     recording[0] = False
     trk.set_option('corr_overlap', 0)
     trk.set_timing(True)
+    # the results copy of a step alone (4.6 MB of records into page-locked memory): the pipeline hides
+    # it behind the next step's kernels as long as it is shorter than a step
+    copy_ms = []
+    for _ in range(6):
+        tc = time.perf_counter()
+        trk.replay_fetch(pins[0].array)
+        copy_ms.append((time.perf_counter() - tc) * 1e3)
+    copy_ms = float(np.median(copy_ms[1:]))
     if dist is not None:
         dt_mine = dt
         tt = torch.tensor([dt], dtype=torch.float64)
@@ -1075,6 +1083,8 @@ def main():
                 # device is the bound) or enqueuing (the host is)
                 'host_us_per_step': round(host_timed['all'] / a.steps / 1e3, 1),
                 'host_wait_us_per_step': round(host_timed['wait'] / a.steps / 1e3, 1),
+                'results_copy_ms': round(copy_ms, 4),
+                'results_copy_mb': round(pins[0].array.nbytes / 1e6, 2),
             },
             'roofline': {
                 'bound': 'hbm', 'kernel': 'trk_span_kernel',
