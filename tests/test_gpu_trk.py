@@ -429,6 +429,59 @@ def test_async_batches_with_different_input_do_not_share_buffers(closed_loop, mo
         p_.free()
 
 
+@pytest.mark.parametrize('mode', [1])
+def test_overlapped_pipelines_return_the_isolated_results(closed_loop, mode):
+    """Option "corr_overlap" = 1: consecutive runs alternate between two streams.  Batches on different
+    IQ in a mixed order, the batch
+    kernels forced (span_single_max = 1), timing modes mixed: every read-back equals the blocking
+    replay of the same input on a fresh handle; then back to the isolated pipeline on the same handle."""
+    from gpsmi.engine import TrkEngine, DeviceBuffer, PinnedArray, OUT_DTYPE
+    _, outs, states, blocks = closed_loop
+    nch = outs.shape[1]
+    nb = 20
+    bufs = []
+    for first in (0, nb):
+        buf = DeviceBuffer(nb * blocks[0].nbytes)
+        for i in range(nb):
+            buf.upload(blocks[first + i], i * blocks[0].nbytes)
+        bufs.append(buf)
+    table, forced = states[:nb], outs['delay_used'][:nb]
+    ref_eng = TrkEngine(max_ch=nch)
+    ref_eng.set_option('span_single_max', 1)
+    want = [ref_eng.replay(b.ptr, nb, table, forced).tobytes() for b in bufs]
+    ref_eng.close()
+    assert want[0] != want[1]
+    eng = TrkEngine(max_ch=nch)
+    eng.set_option('span_single_max', 1)
+    eng.replay_load(nb, table, forced)
+    pins = [PinnedArray((nb, nch), OUT_DTYPE) for _ in range(2)]
+
+    def run(order):
+        for k, which in enumerate(order):
+            pins[k & 1].array.view(np.uint8)[:] = 0xAB
+            eng.set_timing(1 if k % 4 == 0 else 2)
+            eng.replay_run_async(bufs[which].ptr, nb)
+            eng.replay_fetch_async(pins[k & 1].array)
+            eng.wait_prev()
+            if k > 0:
+                assert pins[(k - 1) & 1].array.tobytes() == want[order[k - 1]], (mode, k - 1)
+        eng.wait()
+        assert pins[(len(order) - 1) & 1].array.tobytes() == want[order[-1]]
+
+    eng.set_option('corr_overlap', mode)
+    assert eng.get_option('corr_overlap') == mode
+    run([0, 1, 1, 0, 1, 0, 0, 1, 0, 1, 1])
+    eng.set_option('corr_overlap', 0)
+    run([1, 0, 0, 1])
+    eng.set_option('corr_overlap', mode)             # ... and on again
+    run([0, 0, 1])
+    eng.close()
+    for b in bufs:
+        b.free()
+    for p_ in pins:
+        p_.free()
+
+
 def test_search_ordered_behind_replay_batches(closed_loop):
     """The step of bench.py: a search on its own handle ordered on the device behind the
     previous batch's correlator (gpsmi_acq_after_trk: the dispatch's own completion event),
