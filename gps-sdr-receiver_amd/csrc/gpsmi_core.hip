@@ -44,6 +44,7 @@ static OptDef g_opts[] = {
     {"stream_depth", "GPSMI_STREAM_DEPTH", false, 0},
     {"fold_chunk", "GPSMI_FOLD_CHUNK", false, 0},
     {"epilogue_form", "GPSMI_EPILOGUE_FORM", false, 0},
+    {"copy_stream", "GPSMI_COPY_STREAM", false, 0},
     {"debug_flags", "GPSMI_DEBUG_FLAGS", false, 0},
 };
 static std::mutex g_opts_mutex;

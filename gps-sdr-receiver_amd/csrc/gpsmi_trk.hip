@@ -765,7 +765,8 @@ struct gpsmi_trk {
                                          // the round's final kernels: 50 against 56 us at 64 units, 69 against 63
                                          // at 96, 81 against 66 at 128)
     hipStream_t stream = nullptr;
-    hipStream_t copy_stream = nullptr;   // result read-back, overlaps the next replay run
+    hipStream_t copy_stream = nullptr;   // result read-back, overlaps the next replay run (the epilogue's
+    bool own_copy_stream = false;        // stream unless option "copy_stream" = 1)
     hipStream_t alt_stream = nullptr;    // "corr_overlap": the runs of result slot 1 (slot 0 keeps `stream`)
     hipStream_t epi_stream = nullptr;    // replay: the epilogue of run k beside the code-phase
                                          // correlation of run k + 1 (the other slot's buffers)
@@ -1375,8 +1376,20 @@ int gpsmi_trk_create(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk** out) {
 static int trk_build(const gpsmi_cfg* cfg, int max_ch, gpsmi_trk* h) {
     GPSMI_HIP(hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, cfg->device));
     GPSMI_HIP(hipStreamCreate(&h->stream));
-    GPSMI_HIP(hipStreamCreate(&h->copy_stream));
     GPSMI_HIP(hipStreamCreate(&h->epi_stream));
+    // The read-back of a replay run follows the run's epilogue anyway and is over long before the next
+    // epilogue is due, so by default it shares the epilogue's stream: the HIP runtime maps streams onto
+    // four hardware queues (one per pipe of the command processor), and a process with this handle's
+    // compute and epilogue streams, an acquisition handle's stream and the null stream has four.  A
+    // fifth stream shares a queue with one of them -- which one differs from run to run -- and a step
+    // whose epilogue or search queues behind the compute stream's kernels takes 0.33 ms instead of
+    // 0.23 (GPU_MAX_HW_QUEUES=3 forces it; more queues than pipes cost as much: DESIGN.md 4.6).
+    // Option "copy_stream" = 1 (create time) gives the read-back a stream of its own again.
+    long long own_copy = 0;
+    default_opt("copy_stream", &own_copy, 0);
+    h->own_copy_stream = own_copy != 0;
+    if (h->own_copy_stream) GPSMI_HIP(hipStreamCreate(&h->copy_stream));
+    else h->copy_stream = h->epi_stream;
     GPSMI_HIP(hipEventCreateWithFlags(&h->order, hipEventDisableTiming));
     for (auto& sl : h->slot) {
         for (auto& e : sl.ev) GPSMI_HIP(hipEventCreate(&e));
@@ -1494,7 +1507,7 @@ int gpsmi_trk_destroy(gpsmi_trk* h) {
     }
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
+    if (h->copy_stream && h->own_copy_stream) (void)hipStreamSynchronize(h->copy_stream);
     if (h->epi_stream) (void)hipStreamSynchronize(h->epi_stream);
     void* bufs[] = {h->d_tw, h->d_t32, h->d_rep, h->d_code, h->d_block, h->d_state, h->d_tab_in,
                     h->d_tab_out, h->d_forced, h->slot[0].d_mid, h->slot[1].d_mid, h->slot[0].d_partial,
@@ -1521,7 +1534,7 @@ int gpsmi_trk_destroy(gpsmi_trk* h) {
         if (h->in_done[k]) (void)hipEventDestroy(h->in_done[k]);
     }
     if (h->up_stream) (void)hipStreamDestroy(h->up_stream);
-    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+    if (h->copy_stream && h->own_copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->alt_stream) { (void)hipStreamSynchronize(h->alt_stream); (void)hipStreamDestroy(h->alt_stream); }
     if (h->epi_stream) (void)hipStreamDestroy(h->epi_stream);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -2136,7 +2149,8 @@ int gpsmi_trk_set_option(gpsmi_trk* h, const char* key, long long value) {
     } else if (!strcmp(key, "stream_depth")) {
         if (value < 2 || value > 64) return bad();
         h->stream_depth = (int)value;
-    } else if (!strcmp(key, "correlator") || !strcmp(key, "codephase") || !strcmp(key, "debug_flags")) {
+    } else if (!strcmp(key, "correlator") || !strcmp(key, "codephase") || !strcmp(key, "debug_flags") ||
+               !strcmp(key, "copy_stream")) {
         return fail(GPSMI_E_STATE, "gpsmi_trk_set_option: '%s' is taken at create time (gpsmi_set_default)", key);
     } else {
         return fail(GPSMI_E_ARG, "gpsmi_trk_set_option: unknown option '%s'", key);
@@ -2170,6 +2184,7 @@ int gpsmi_trk_get_option(gpsmi_trk* h, const char* key, long long* value) {
     else if (!strcmp(key, "correlator")) *value = (h->mfma == 4 || h->span8) ? 1 : 0;     // what runs, not what was asked
     else if (!strcmp(key, "codephase")) *value = h->general ? (h->pfa ? 0 : (h->big ? 2 : 1)) : 0;
     else if (!strcmp(key, "debug_flags")) *value = h->P.flags;
+    else if (!strcmp(key, "copy_stream")) *value = h->own_copy_stream ? 1 : 0;
     else return fail(GPSMI_E_ARG, "gpsmi_trk_get_option: unknown option '%s'", key);
     return GPSMI_OK;
 }
