@@ -76,6 +76,11 @@ int gpsmi_abi_sizeof(int which);
  *   "codephase"         code_samples != 2048 only: 0 (default) native 16368-point LDS correlation
  *                       / zero-padded 32768-point pair, 1 the exact time-domain kernel, 2 the
  *                       32768-point pair at 16368 too (env GPSMI_DIRECT_CORR)
+ *   "copy_stream"       0 (default): the read-back of a replay run (gpsmi_trk_replay_fetch_async) goes to
+ *                       the stream of the run's epilogue, which it follows anyway; 1: to a stream of
+ *                       its own.  The HIP runtime maps streams onto four hardware queues; with the
+ *                       compute and epilogue streams of this handle, an acquisition handle's stream
+ *                       and the null stream a process has four (env GPSMI_COPY_STREAM)
  * keys a live tracking handle accepts as well (see DESIGN.md for the measurements behind them):
  *   "corr_cg"           channels per code-phase-correlation workgroup in batches: 2, 4 (default), 6
  *   "corr_small1/2"     jobs per launch up to which 1 / 2 channels per workgroup are taken (384, 1536)
