@@ -76,17 +76,21 @@ __global__ __launch_bounds__(256, (CG > 4 || CG == 1) ? 2 : 3) void trk_corr_ker
     __shared__ float red[kStatsRedFloats];
     // Two small arrays live inside the second FFT buffer, which a transform leaves free when it
     // returns and does not write before its first barrier: the magnitudes of the statistics
-    // (8 KiB) and the row factors of the fold (1 KiB, used before any transform).  41.2 KiB of
-    // LDS per workgroup, three workgroups per CU at CG = 4 by the registers (162 VGPRs, capped
+    // (8 KiB) and the row factors of the fold (1 KiB, used before any transform).  39.3 KiB of
+    // LDS per workgroup, three workgroups per CU at CG = 4 by the registers (160 VGPRs, capped
     // at 168 by the launch bounds); CG = 2 (four workgroups per CU, the fold's rows read six
-    // times per block instead of three) measured 10 % slower per batch.
+    // times per block instead of three) measured 10 % slower per batch; CG = 4 compiled for four
+    // workgroups per CU (128 registers: 68-128 bytes of scratch, the per-thread twiddles of the
+    // transforms reloaded in front of every pass) 25 % slower (round 4: 0.162-0.165 against 0.131 ms).
     float* magbuf = lds + 2 * kFftPlane;
     float2 (*urow)[32] = reinterpret_cast<float2 (*)[32]>(lds + 2 * kFftPlane);   // U[c][i], i = row
-    static_assert(kFftN <= 2 * kFftPlane1 && CG * 32 * 2 <= 2 * kFftPlane1, "aliases must fit buffer 1");
-    __shared__ float2 step[CG];                  // exp(-j w 256/fs)
+    // (round 4: the factors of V(t) and the 256-position step live there too -- V is applied to all
+    // channels' folds right behind the fold, before the first transform touches the buffer)
+    float2 (*vtab)[32] = urow + CG;              // the factors of V(t), see the prologue
+    float2* step = reinterpret_cast<float2*>(urow + 2 * CG);     // exp(-j w 256/fs)
+    static_assert(kFftN <= 2 * kFftPlane1 && (CG * 64 + CG) * 2 <= 2 * kFftPlane1, "aliases must fit buffer 1");
     __shared__ StreamChan schan[CG];
     __shared__ CorrFin fin[CG];
-    __shared__ float2 vtab[CG][32];              // the factors of V(t), see the prologue
 
     // batches: the channel groups of a block are neighbours on one XCD (they share its rows through
     // that L2); fewer than 8 blocks (the closed loop) map linearly: gpsmi_wgmap.h
@@ -236,16 +240,20 @@ __global__ __launch_bounds__(256, (CG > 4 || CG == 1) ? 2 : 3) void trk_corr_ker
     const float sc = (1.0f / (float)P.corr_avg) * (1.0f / kFftN);
     // V(m) for m = t + 256 r (base phasor and seven steps of 256 positions) applied to the fold;
     // the replica spectrum is fetched at the same time so that its latency hides behind the FFT
-    auto prepare = [&](int c, const StreamChan& s, float2 (&v)[8], float2 (&rs)[8]) {
+#pragma unroll
+    for (int c = 0; c < CG; ++c) {
         const float2 e1 = vtab[c][t & 15], e2 = vtab[c][16 + (t >> 4)], s2 = step[c];
         fft_c vm = cmulp(fft_c{e1.x, e1.y}, fft_c{e2.x, e2.y});
         const fft_c st256 = fft_c{s2.x, s2.y};
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            const fft_c o = cmulp(acc[c][r] * sc, vm);                // (packed: two instructions each)
-            v[r] = make_float2(o.x, o.y);
+            acc[c][r] = cmulp(acc[c][r] * sc, vm);                    // (packed: two instructions each)
             vm = cmulp(vm, st256);
         }
+    }
+    auto prepare = [&](int c, const StreamChan& s, float2 (&v)[8], float2 (&rs)[8]) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = make_float2(acc[c][r].x, acc[c][r].y);
         const float2* R = rep + (size_t)s.prn * kFftN;
 #pragma unroll
         for (int q = 0; q < 8; ++q) rs[q] = R[t + 256 * q];
