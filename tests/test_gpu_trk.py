@@ -171,6 +171,70 @@ def test_batch_epilogue_forms_reproduce_closed_loop(closed_loop, form):
             assert nxt[i, c]['df'][:n].tobytes() == states[i + 1, c]['df'][:n].tobytes()
 
 
+def test_batch_epilogue_forms_agree_on_random_states(closed_loop):
+    """Differential test of the two batch epilogues (option "epilogue_form") on state rows the closed
+    loop does not visit often: forced delay 0 with and without a carry (33 dumps / the rows are the
+    windows), every edge_state, locked and unlocked, drift lists of every length 1 .. 32, both signs
+    of PREV_SIGNAL, FREQ at and beyond the clamp.  Same IQ, same table: records bytewise, next states
+    field by field."""
+    from gpsmi.engine import TrkEngine, DeviceBuffer, STATE_DTYPE
+    _, outs, states, blocks = closed_loop
+    nb, nch = outs.shape
+    rng = np.random.default_rng(20260405)
+    table = states.copy()
+    forced = outs['delay_used'].copy()
+    for i in range(nb):
+        for c in range(nch):
+            st = table[i, c]
+            kind = rng.integers(0, 6)
+            if kind == 0:                     # no carry, delay 0: the rows are the windows
+                st['nps'] = 0
+                forced[i, c] = 0
+            elif kind == 1:                   # a carry and delay 0: N_CYC + 1 dumps
+                st['nps'] = int(rng.integers(1, 2048))
+                forced[i, c] = 0
+            elif kind == 2:
+                st['nps'] = int(rng.integers(0, 2049))
+                forced[i, c] = int(rng.integers(1, 2048))
+            st['prev_sum_re'] = np.float32(rng.normal() * 3)
+            st['prev_sum_im'] = np.float32(rng.normal() * 3)
+            st['phase_locked'] = int(rng.integers(0, 2))
+            st['edge_state'] = int(rng.integers(-1, 3))
+            st['prev_signal'] = np.float32(rng.normal() * 0.05) if rng.integers(0, 4) else np.float32(0)
+            st['std_dev'] = np.float32(abs(rng.normal()) * 0.01)
+            n = int(rng.integers(1, 33))
+            st['df_len'] = n
+            st['df'][:n] = (rng.normal(size=n) * 0.3).astype(np.float32)
+            if rng.integers(0, 8) == 0:       # FREQ about to be clamped
+                st['freq'] = np.float32(4999.9 if rng.integers(0, 2) else -4999.9)
+                st['omega0'] = 0.0
+            table[i, c] = st
+    buf = DeviceBuffer(nb * blocks[0].nbytes)
+    for i, b in enumerate(blocks):
+        buf.upload(b, i * b.nbytes)
+    got = []
+    for form in (0, 1):
+        eng = TrkEngine(max_ch=nch)
+        eng.set_option('span_single_max', 1)
+        eng.set_option('epilogue_form', form)
+        rep = eng.replay(buf.ptr, nb, table, forced)
+        nxt = eng.replay_states(nb)
+        eng.close()
+        got.append((rep, nxt))
+    buf.free()
+    (r0, n0), (r1, n1) = got
+    assert set(np.unique(r0['n_dumps'])) >= {32, 33}
+    assert r0.tobytes() == r1.tobytes()
+    for k in STATE_DTYPE.names:
+        if k == 'df':
+            continue
+        assert n0[k].tobytes() == n1[k].tobytes(), k
+    for i in range(nb):
+        for c in range(nch):
+            n = int(n0[i, c]['df_len'])
+            assert n0[i, c]['df'][:n].tobytes() == n1[i, c]['df'][:n].tobytes(), (i, c)
+
+
 def test_replay_without_forced_delay(closed_loop):
     """With no recorded DELAY given, replay derives it from each block's own
     correlation, exactly as the closed loop does."""
