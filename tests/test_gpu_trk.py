@@ -171,16 +171,20 @@ def test_batch_epilogue_forms_reproduce_closed_loop(closed_loop, form):
             assert nxt[i, c]['df'][:n].tobytes() == states[i + 1, c]['df'][:n].tobytes()
 
 
-def test_batch_epilogue_forms_agree_on_random_states(closed_loop):
+@pytest.mark.parametrize('n_cyc', [32, 16, 8])
+def test_batch_epilogue_forms_agree_on_random_states(closed_loop, n_cyc):
     """Differential test of the two batch epilogues (option "epilogue_form") on state rows the closed
     loop does not visit often: forced delay 0 with and without a carry (33 dumps / the rows are the
     windows), every edge_state, locked and unlocked, drift lists of every length 1 .. 32, both signs
     of PREV_SIGNAL, FREQ at and beyond the clamp.  Same IQ, same table: records bytewise, next states
-    field by field."""
-    from gpsmi.engine import TrkEngine, DeviceBuffer, STATE_DTYPE
+    field by field.  The other block lengths (five / three / two dumps per lane) take the first N_CYC
+    code periods of the same blocks."""
+    from gpsmi.engine import TrkEngine, DeviceBuffer, STATE_DTYPE, Config
     _, outs, states, blocks = closed_loop
     nb, nch = outs.shape
-    rng = np.random.default_rng(20260405)
+    blocks = [np.ascontiguousarray(b[:n_cyc * 2048]) for b in blocks]
+    df_no = 1024 // n_cyc
+    rng = np.random.default_rng(20260405 + n_cyc)
     table = states.copy()
     forced = outs['delay_used'].copy()
     for i in range(nb):
@@ -202,7 +206,7 @@ def test_batch_epilogue_forms_agree_on_random_states(closed_loop):
             st['edge_state'] = int(rng.integers(-1, 3))
             st['prev_signal'] = np.float32(rng.normal() * 0.05) if rng.integers(0, 4) else np.float32(0)
             st['std_dev'] = np.float32(abs(rng.normal()) * 0.01)
-            n = int(rng.integers(1, 33))
+            n = int(rng.integers(1, df_no + 1))
             st['df_len'] = n
             st['df'][:n] = (rng.normal(size=n) * 0.3).astype(np.float32)
             if rng.integers(0, 8) == 0:       # FREQ about to be clamped
@@ -214,7 +218,7 @@ def test_batch_epilogue_forms_agree_on_random_states(closed_loop):
         buf.upload(b, i * b.nbytes)
     got = []
     for form in (0, 1):
-        eng = TrkEngine(max_ch=nch)
+        eng = TrkEngine(Config(n_cyc=n_cyc), max_ch=nch)
         eng.set_option('span_single_max', 1)
         eng.set_option('epilogue_form', form)
         rep = eng.replay(buf.ptr, nb, table, forced)
@@ -223,7 +227,7 @@ def test_batch_epilogue_forms_agree_on_random_states(closed_loop):
         got.append((rep, nxt))
     buf.free()
     (r0, n0), (r1, n1) = got
-    assert set(np.unique(r0['n_dumps'])) >= {32, 33}
+    assert set(np.unique(r0['n_dumps'])) >= {n_cyc, n_cyc + 1}
     assert r0.tobytes() == r1.tobytes()
     for k in STATE_DTYPE.names:
         if k == 'df':
