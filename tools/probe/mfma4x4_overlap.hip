@@ -72,11 +72,14 @@ void run(int wg, float* out, long long* cyc) {
 
 int main() {
     float* out; long long* cyc;
-    hipMalloc(&out, 256 * 3 * 256 * sizeof(float)); hipMalloc(&cyc, 16);
+    hipMalloc(&out, 256 * 8 * 256 * sizeof(float)); hipMalloc(&cyc, 16);
     printf("per iteration: 16 MFMA 4x4x1 (mode 0), 32 v_pk_fma_f32 (mode 1), both in one wave (2), split by workgroup (3)\n");
     for (int wg = 1; wg <= 3; ++wg) {
         run<0>(wg, out, cyc); run<1>(wg, out, cyc); run<2>(wg, out, cyc);
         if (wg > 1) run<3>(wg, out, cyc);
+    }
+    for (int wg = 4; wg <= 8; ++wg) {      // the issue rate of each kind alone at higher occupancy
+        run<0>(wg, out, cyc); run<1>(wg, out, cyc);
     }
     return 0;
 }
